@@ -1,0 +1,172 @@
+/* smnngp.h — C-ABI of libsmnngp.so: the MI355X (gfx950) scale-mixture NNGP hot path.
+ *
+ * Drop-in boundary for ONE path of Hyungi-Lee/Scale-Mixtures-of-Neural-Network-Gaussian-Processes:
+ * NNGP/NTK kernel-matrix build -> jittered Cholesky -> triangular solves -> Gaussian / Student-t
+ * log-marginal-likelihood and predictive mean / covariance.  The reference has no FFI of its own
+ * (it is pure Python over JAX + neural_tangents); every entry point below names the reference
+ * call (file:line under /root/reference) whose arithmetic it replaces.  The Python side binds this
+ * header with ctypes; there are no torch / JAX types anywhere in the ABI.
+ *
+ * Conventions
+ *   - every function returns int status: SMN_OK (0) or a negative SMN_E* code; the message is
+ *     kept per context and read with smn_last_error().  Nothing throws across the ABI.
+ *   - matrices are dense row-major with an explicit leading dimension (elements, not bytes).
+ *   - "d" pointers are DEVICE pointers obtained from smn_malloc(); "h" pointers are host memory
+ *     borrowed for the duration of the call.  dtype: SMN_F32 / SMN_F64.
+ *   - calls are stream-ordered on the context's stream; functions that return host scalars
+ *     synchronise that stream.  A context is not thread-safe.
+ *   - numerical failure is NOT an error status: a non-positive pivot is reported through *info
+ *     (1-based index of the first bad pivot, 0 = fine) and the dependent outputs are NaN, which is
+ *     what the reference's JAX Cholesky does (silent NaN, experiments/regression/train.py:211).
+ */
+#ifndef SMNNGP_H
+#define SMNNGP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct smn_ctx smn_ctx;
+
+enum { SMN_OK = 0, SMN_EINVAL = -1, SMN_EHIP = -2, SMN_ENOMEM = -3, SMN_ENOTSUP = -4, SMN_ECOMM = -5 };
+enum { SMN_F32 = 0, SMN_F64 = 1 };
+enum { SMN_ACT_RELU = 0, SMN_ACT_ERF = 1 };            /* experiments/nt_kernels.py:12-18           */
+enum { SMN_GET_NNGP = 1, SMN_GET_NTK = 2 };            /* kernel_fn(..., get=) bit mask             */
+enum { SMN_FILL_FULL = 0, SMN_FILL_LOWER = 1 };        /* symmetric build: mirror or lower triangle */
+enum { SMN_NET_MLP = 0, SMN_NET_DENSE_RESNET = 1 };    /* nt_kernels.py:21-31 / :83-103             */
+
+/* ---- context, errors, memory (JAX array semantics: the spax modules never manage memory themselves) ---- */
+int smn_version(void);
+int smn_device_count(int* n);
+int smn_ctx_create(int device_id, smn_ctx** out);
+int smn_ctx_destroy(smn_ctx* ctx);
+int smn_last_error(smn_ctx* ctx, char* buf, size_t n);
+int smn_synchronize(smn_ctx* ctx);
+int smn_malloc(smn_ctx* ctx, size_t bytes, void** dptr);
+int smn_free(smn_ctx* ctx, void* dptr);
+int smn_memset(smn_ctx* ctx, void* dptr, int value, size_t bytes);
+int smn_memcpy_h2d(smn_ctx* ctx, void* dst_d, const void* src_h, size_t bytes);
+int smn_memcpy_d2h(smn_ctx* ctx, void* dst_h, const void* src_d, size_t bytes);
+int smn_memcpy_d2d(smn_ctx* ctx, void* dst_d, const void* src_d, size_t bytes);
+/* 2-D copies (row pitch in bytes) used to move unpadded host matrices into padded device ones */
+int smn_memcpy2d_h2d(smn_ctx* ctx, void* dst_d, size_t dpitch, const void* src_h, size_t spitch,
+                     size_t width_bytes, size_t rows);
+int smn_memcpy2d_d2h(smn_ctx* ctx, void* dst_h, size_t dpitch, const void* src_d, size_t spitch,
+                     size_t width_bytes, size_t rows);
+/* timing hooks (hipEvents on the context's stream) */
+int smn_timer_start(smn_ctx* ctx);
+int smn_timer_stop_ms(smn_ctx* ctx, double* ms);           /* synchronises */
+
+/* ---- NNGP / NTK kernel build ----
+ * Replaces kernel_fn(x1, x2, get) produced by get_mlp_kernel / get_dense_resnet_kernel
+ * (experiments/nt_kernels.py:21-31, :83-103; called from spax/kernels.py:23-27 and
+ * experiments/regression/find.py:64-70): K0 = x1 x2^T / d on MFMA, then num_hiddens x
+ * [Dense(w_std,b_std); act] and Dense(last_w_std, b=0) fused into the GEMM epilogue.
+ *   x1_d [n1,d] ld=ldx1; x2_d [n2,d] or NULL (symmetric: x2 = x1, fill selects mirror/lower).
+ *   get_mask: SMN_GET_NNGP | SMN_GET_NTK; nngp_d [n1,n2] ld=ldk (may be NULL if not requested),
+ *   ntk_d likewise. */
+int smn_kernel_mlp(smn_ctx* ctx, int dtype, int net, int act, int num_hiddens,
+                   double w_std, double b_std, double last_w_std,
+                   const void* x1_d, int64_t n1, int64_t ldx1,
+                   const void* x2_d, int64_t n2, int64_t ldx2, int64_t d,
+                   int get_mask, int fill,
+                   void* nngp_d, void* ntk_d, int64_t ldk);
+
+/* Row-sharded variant (multi-GPU build): computes rows [row_begin,row_end)
+ * of the symmetric kernel of x_d against all n columns into out_d [(row_end-row_begin), n]. */
+int smn_kernel_mlp_rows(smn_ctx* ctx, int dtype, int net, int act, int num_hiddens,
+                        double w_std, double b_std, double last_w_std,
+                        const void* x_d, int64_t n, int64_t ldx, int64_t d,
+                        int64_t row_begin, int64_t row_end, int get_mask,
+                        void* nngp_rows_d, void* ntk_rows_d, int64_t ldk);
+
+/* The two halves of the build, exposed separately for sweeps that reuse K0 across (w_std,b_std)
+ * (experiments/regression/find.py:134-138) and for roofline measurement of the recursion alone.
+ * smn_gram: k0_d = x1 x2^T / d (+ q1_d [n1], q2_d [n2] diagonals ||x||^2/d).
+ * smn_recursion: applies the layer stack elementwise to k0 (HBM-streaming kernel). */
+int smn_gram(smn_ctx* ctx, int dtype, const void* x1_d, int64_t n1, int64_t ldx1,
+             const void* x2_d, int64_t n2, int64_t ldx2, int64_t d,
+             void* k0_d, int64_t ldk, void* q1_d, void* q2_d);
+int smn_recursion(smn_ctx* ctx, int dtype, int net, int act, int num_hiddens,
+                  double w_std, double b_std, double last_w_std,
+                  const void* k0_d, int64_t n1, int64_t n2, int64_t ldk0,
+                  const void* q1_d, const void* q2_d, int symmetric, int get_mask,
+                  void* nngp_d, void* ntk_d, int64_t ldk);
+
+/* conv-NNGP (experiments/nt_kernels.py:34-45): x [n,H,W,C] NHWC, 3x3 SAME stride 1, Flatten, Dense. */
+int smn_kernel_cnn(smn_ctx* ctx, int dtype, int act, int num_hiddens,
+                   double w_std, double b_std, double last_w_std,
+                   const void* x1_d, int64_t n1, const void* x2_d, int64_t n2,
+                   int64_t H, int64_t W, int64_t C, int fill, void* nngp_d, int64_t ldk);
+
+/* ---- factorisation and solves ----
+ * smn_cholesky: in-place lower Cholesky of the leading n_factor x n_factor block of the symmetric
+ * matrix a_d [n_total,n_total] (lower triangle read/written), carried through the remaining
+ * n_total-n_factor rows: on return rows >= n_factor hold B L^-T in their first n_factor columns
+ * and the Schur complement C - B A^-1 B^T in the trailing block (lower triangle).  With
+ * n_total == n_factor this is a plain potrf.  Before factoring, jitter_abs + ridge_rel*tr(A)/n
+ * is added to the first n_shift diagonal entries: jitter_abs is spax/utils.py:26-27 +
+ * spax/models.py:96 (absolute), ridge_rel is neural_tangents' diag_reg scaling used by
+ * spax/kernels.py:29-32 (trace taken over those n_shift entries).
+ * Replaces lax.linalg.cholesky + triangular_solve (spax/utils.py:179-180), the Cholesky inside
+ * jax.scipy.stats.multivariate_normal.logpdf (spax/likelihoods.py:27) and cho_factor/cho_solve
+ * inside gradient_descent_mse_ensemble.  *logdet_h = 2 sum log L_ii over n_factor columns. */
+int smn_cholesky(smn_ctx* ctx, int dtype, void* a_d, int64_t n_total, int64_t n_factor, int64_t lda,
+                 int64_t n_shift, double jitter_abs, double ridge_rel, int* info_h, double* logdet_h);
+
+/* X = op(L)^-1 B in place, B [n,nrhs] row-major ld=ldb, L lower [n,n]; trans=0: L, 1: L^T.
+ * (lax.linalg.triangular_solve, spax/utils.py:180.) */
+int smn_trsm(smn_ctx* ctx, int dtype, const void* l_d, int64_t n, int64_t ldl,
+             void* b_d, int64_t nrhs, int64_t ldb, int trans);
+
+/* ---- likelihood heads (host scalars out) ----
+ * smn_lml: log-marginal likelihood of y_d [n] under cov = K + eps I, K given as k_d [n,n] lower
+ * (destroyed: overwritten by its factor).  df <= 0: Gaussian (spax/likelihoods.py:25-28);
+ * df > 0: multivariate Student-t with shape = scale*cov, df = 2a, scale = b/a
+ * (spax/likelihoods.py:45-50, spax/utils.py:178-183).  NaN + info>0 when not PD. */
+int smn_lml(smn_ctx* ctx, int dtype, void* k_d, int64_t n, int64_t ldk, const void* y_d,
+            double eps_abs, double df, double scale, double* logpdf_h, double* quad_h,
+            double* logdet_h, int* info_h);
+
+/* smn_predict: t=infinity NNGP posterior (spax/kernels.py:29-32 -> neural_tangents
+ * gradient_descent_mse_ensemble).  kj_d is the JOINT kernel of [x_train; x_test] ([n+t, n+t],
+ * lower triangle, destroyed).  y_d [n,c] row-major.  mean_d [t,c], cov_d [t,t] (full, symmetric).
+ * ridge_rel = diag_reg (relative: * tr(K_dd)/n); ridge_abs adds an absolute term.
+ * quad_h (may be NULL) receives y_k^T K~^-1 y_k for each output column k. */
+int smn_predict(smn_ctx* ctx, int dtype, void* kj_d, int64_t n, int64_t t, int64_t ldk,
+                const void* y_d, int64_t c, double ridge_rel, double ridge_abs,
+                void* mean_d, void* cov_d, int64_t ldcov, double* quad_h, double* logdet_h, int* info_h);
+
+/* ---- fused model-level calls (what the spax facade uses; nothing leaves the GPU but scalars) ----
+ * smn_spr_loss: SPR.loss (spax/models.py:93-98): builds K(x,x) straight into the factorisation
+ * workspace, adds eps_abs, factors, and returns the log-pdf of y (Gaussian df<=0 / Student-t). */
+int smn_spr_loss(smn_ctx* ctx, int dtype, int net, int act, int num_hiddens,
+                 double w_std, double b_std, double last_w_std,
+                 const void* x_d, int64_t n, int64_t ldx, int64_t d, const void* y_d,
+                 double eps_abs, double df, double scale,
+                 double* logpdf_h, double* quad_h, double* logdet_h, int* info_h);
+/* smn_spr_predict: NNGPKernel.predict (spax/kernels.py:29-32) from the raw inputs: joint kernel of
+ * [x; x_test], relative/absolute ridge on the training block, posterior mean [t,c] and cov [t,t]. */
+int smn_spr_predict(smn_ctx* ctx, int dtype, int net, int act, int num_hiddens,
+                    double w_std, double b_std, double last_w_std,
+                    const void* x_d, int64_t n, int64_t ldx, const void* xt_d, int64_t t, int64_t ldxt,
+                    int64_t d, const void* y_d, int64_t c, double ridge_rel, double ridge_abs,
+                    void* mean_d, void* cov_d, int64_t ldcov,
+                    double* quad_h, double* logdet_h, int* info_h);
+
+/* ---- multi-GPU (nothing in the reference to mirror) ----
+ * One process per GPU.  Rank 0 calls smn_comm_unique_id and ships the 128 bytes to the other
+ * ranks by any host channel; every rank then calls smn_comm_init.  smn_allgather is an RCCL
+ * all-gather of `count` elements per rank on the context's stream. */
+int smn_comm_unique_id(char id_out[128]);
+int smn_comm_init(smn_ctx* ctx, int nranks, int rank, const char id[128]);
+int smn_comm_destroy(smn_ctx* ctx);
+int smn_allgather(smn_ctx* ctx, int dtype, const void* send_d, void* recv_d, int64_t count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SMNNGP_H */

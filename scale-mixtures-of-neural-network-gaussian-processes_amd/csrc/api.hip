@@ -1,0 +1,282 @@
+// api.hip — context, memory and utility entry points of the C-ABI (include/smnngp.h).
+#include "internal.hpp"
+
+int smn_workspace(smn_ctx* ctx, int slot, size_t bytes, void** out) {
+  if (slot < 0 || slot >= 4) return smn_fail(ctx, SMN_EINVAL, "bad workspace slot");
+  if (ctx->ws_bytes[slot] < bytes) {
+    if (ctx->ws[slot]) {
+      SMN_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      SMN_HIP(ctx, hipFree(ctx->ws[slot]));
+      ctx->ws[slot] = nullptr;
+      ctx->ws_bytes[slot] = 0;
+    }
+    const size_t want = bytes + bytes / 8 + 4096;
+    SMN_HIP(ctx, hipMalloc(&ctx->ws[slot], want));
+    ctx->ws_bytes[slot] = want;
+  }
+  *out = ctx->ws[slot];
+  return SMN_OK;
+}
+
+namespace {
+
+template <typename T>
+__global__ void copy_matrix_kernel(T* __restrict__ dst, int64_t ldd, const T* __restrict__ src, int64_t lds,
+                                   int64_t rows, int64_t cols, int lower_only) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  for (int64_t r = blockIdx.y; r < rows; r += gridDim.y) {
+    if (lower_only && c > r) continue;
+    dst[r * ldd + c] = src[r * lds + c];
+  }
+}
+
+template <typename T>
+__global__ void transpose_kernel(T* __restrict__ dst, int64_t ldd, const T* __restrict__ src, int64_t lds,
+                                 int64_t rows, int64_t cols) {
+  __shared__ T tile[32][33];
+  const int64_t c0 = (int64_t)blockIdx.x * 32, r0 = (int64_t)blockIdx.y * 32;
+  for (int i = threadIdx.y; i < 32; i += 8) {
+    const int64_t r = r0 + i, c = c0 + threadIdx.x;
+    tile[i][threadIdx.x] = (r < rows && c < cols) ? src[r * lds + c] : T(0);
+  }
+  __syncthreads();
+  for (int i = threadIdx.y; i < 32; i += 8) {
+    const int64_t c = c0 + i, r = r0 + threadIdx.x;   // dst row = src col
+    if (c < cols && r < rows) dst[c * ldd + r] = tile[threadIdx.x][i];
+  }
+}
+
+template <typename T>
+__global__ void identity_pad_kernel(T* __restrict__ a, int64_t lda, int64_t n_pad, int64_t n_valid) {
+  const int64_t i = n_valid + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_pad) a[i * lda + i] = T(1);
+}
+
+template <typename T>
+__global__ void set_aug_rows_kernel(T* __restrict__ a, int64_t lda, int64_t row0, int64_t ncols,
+                                    const T* __restrict__ y, int64_t n, int64_t c, int64_t ldy) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t k = blockIdx.y;
+  if (i >= ncols || k >= c) return;
+  a[(row0 + k) * lda + i] = i < n ? y[i * ldy + k] : T(0);
+}
+
+// mean[ti, k] = -a[aug0 + t + k, aug0 + ti];  cov[ti, tj] = a[aug0 + max, aug0 + min];
+// quad[k] = -a[aug0 + t + k, aug0 + t + k]
+template <typename T>
+__global__ void extract_posterior_kernel(const T* __restrict__ a, int64_t lda, int64_t aug0, int64_t t, int64_t c,
+                                         T* __restrict__ mean, T* __restrict__ cov, int64_t ldcov,
+                                         double* __restrict__ quad) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (int64_t i = blockIdx.y; i <= t; i += gridDim.y)
+  if (i < t) {
+    if (j < t && cov) {
+      const int64_t hi = i > j ? i : j, lo = i > j ? j : i;
+      cov[i * ldcov + j] = a[(aug0 + hi) * lda + aug0 + lo];
+    }
+    if (j < c && mean) mean[i * c + j] = -a[(aug0 + t + j) * lda + aug0 + i];
+  } else if (i == t) {
+    if (j < c && quad) quad[j] = -(double)a[(aug0 + t + j) * lda + aug0 + t + j];
+  }
+}
+
+}  // namespace
+
+#define DISPATCH_T(dtype, expr_f32, expr_f64) \
+  do {                                        \
+    if ((dtype) == SMN_F64) { expr_f64; } else { expr_f32; } \
+  } while (0)
+
+int fill_identity_pad(smn_ctx* ctx, int dtype, void* a, int64_t lda, int64_t n_pad, int64_t n_valid) {
+  if (n_pad <= n_valid) return SMN_OK;
+  const unsigned g = (unsigned)((n_pad - n_valid + 255) / 256);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(identity_pad_kernel<float>, dim3(g), dim3(256), 0, ctx->stream, static_cast<float*>(a), lda, n_pad, n_valid),
+             hipLaunchKernelGGL(identity_pad_kernel<double>, dim3(g), dim3(256), 0, ctx->stream, static_cast<double*>(a), lda, n_pad, n_valid));
+  SMN_CHECK_LAUNCH(ctx);
+  return SMN_OK;
+}
+
+int copy_matrix(smn_ctx* ctx, int dtype, void* dst, int64_t ldd, const void* src, int64_t lds, int64_t rows,
+                int64_t cols, int lower_only) {
+  if (rows <= 0 || cols <= 0) return SMN_OK;
+  dim3 g((unsigned)((cols + 255) / 256), (unsigned)(rows < 32768 ? rows : 32768));
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(copy_matrix_kernel<float>, g, dim3(256), 0, ctx->stream, static_cast<float*>(dst), ldd, static_cast<const float*>(src), lds, rows, cols, lower_only),
+             hipLaunchKernelGGL(copy_matrix_kernel<double>, g, dim3(256), 0, ctx->stream, static_cast<double*>(dst), ldd, static_cast<const double*>(src), lds, rows, cols, lower_only));
+  SMN_CHECK_LAUNCH(ctx);
+  return SMN_OK;
+}
+
+int transpose_matrix(smn_ctx* ctx, int dtype, void* dst, int64_t ldd, const void* src, int64_t lds, int64_t rows,
+                     int64_t cols) {
+  if (rows <= 0 || cols <= 0) return SMN_OK;
+  dim3 g((unsigned)((cols + 31) / 32), (unsigned)((rows + 31) / 32)), b(32, 8);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(transpose_kernel<float>, g, b, 0, ctx->stream, static_cast<float*>(dst), ldd, static_cast<const float*>(src), lds, rows, cols),
+             hipLaunchKernelGGL(transpose_kernel<double>, g, b, 0, ctx->stream, static_cast<double*>(dst), ldd, static_cast<const double*>(src), lds, rows, cols));
+  SMN_CHECK_LAUNCH(ctx);
+  return SMN_OK;
+}
+
+int set_aug_rows(smn_ctx* ctx, int dtype, void* a, int64_t lda, int64_t row0, int64_t ncols, const void* y, int64_t n,
+                 int64_t c, int64_t ldy) {
+  if (c <= 0) return SMN_OK;
+  dim3 g((unsigned)((ncols + 255) / 256), (unsigned)c);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(set_aug_rows_kernel<float>, g, dim3(256), 0, ctx->stream, static_cast<float*>(a), lda, row0, ncols, static_cast<const float*>(y), n, c, ldy),
+             hipLaunchKernelGGL(set_aug_rows_kernel<double>, g, dim3(256), 0, ctx->stream, static_cast<double*>(a), lda, row0, ncols, static_cast<const double*>(y), n, c, ldy));
+  SMN_CHECK_LAUNCH(ctx);
+  return SMN_OK;
+}
+
+int extract_posterior(smn_ctx* ctx, int dtype, const void* a, int64_t lda, int64_t aug0, int64_t t, int64_t c,
+                      void* mean, void* cov, int64_t ldcov, double* quad_dev) {
+  const int64_t w = t > c ? t : c;
+  dim3 g((unsigned)((w + 255) / 256), (unsigned)(t + 1 < 32768 ? t + 1 : 32768));
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(extract_posterior_kernel<float>, g, dim3(256), 0, ctx->stream, static_cast<const float*>(a), lda, aug0, t, c, static_cast<float*>(mean), static_cast<float*>(cov), ldcov, quad_dev),
+             hipLaunchKernelGGL(extract_posterior_kernel<double>, g, dim3(256), 0, ctx->stream, static_cast<const double*>(a), lda, aug0, t, c, static_cast<double*>(mean), static_cast<double*>(cov), ldcov, quad_dev));
+  SMN_CHECK_LAUNCH(ctx);
+  return SMN_OK;
+}
+
+// ------------------------------------------------------------------ public API
+extern "C" int smn_version(void) { return 100; }
+
+extern "C" int smn_device_count(int* n) {
+  if (!n) return SMN_EINVAL;
+  int c = 0;
+  if (hipGetDeviceCount(&c) != hipSuccess) c = 0;
+  *n = c;
+  return SMN_OK;
+}
+
+extern "C" int smn_ctx_create(int device_id, smn_ctx** out) {
+  if (!out) return SMN_EINVAL;
+  *out = nullptr;
+  int cnt = 0;
+  if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0 || device_id < 0 || device_id >= cnt) return SMN_EHIP;
+  if (hipSetDevice(device_id) != hipSuccess) return SMN_EHIP;
+  smn_ctx* c = new smn_ctx();
+  c->device = device_id;
+  bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
+            hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) == hipSuccess &&
+            hipEventCreateWithFlags(&c->ev_a, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&c->ev_b, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreate(&c->ev_t0) == hipSuccess && hipEventCreate(&c->ev_t1) == hipSuccess &&
+            hipMalloc(reinterpret_cast<void**>(&c->d_scal), 64 * sizeof(double)) == hipSuccess &&
+            hipMalloc(reinterpret_cast<void**>(&c->d_info), 16 * sizeof(int)) == hipSuccess;
+  if (!ok) {
+    smn_ctx_destroy(c);
+    return SMN_EHIP;
+  }
+  *out = c;
+  return SMN_OK;
+}
+
+extern "C" int smn_ctx_destroy(smn_ctx* c) {
+  if (!c) return SMN_OK;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->comm) smn_comm_destroy(c);
+  for (int i = 0; i < 4; ++i)
+    if (c->ws[i]) (void)hipFree(c->ws[i]);
+  if (c->d_scal) (void)hipFree(c->d_scal);
+  if (c->d_info) (void)hipFree(c->d_info);
+  if (c->ev_a) (void)hipEventDestroy(c->ev_a);
+  if (c->ev_b) (void)hipEventDestroy(c->ev_b);
+  if (c->ev_t0) (void)hipEventDestroy(c->ev_t0);
+  if (c->ev_t1) (void)hipEventDestroy(c->ev_t1);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  if (c->stream2) (void)hipStreamDestroy(c->stream2);
+  delete c;
+  return SMN_OK;
+}
+
+extern "C" int smn_last_error(smn_ctx* ctx, char* buf, size_t n) {
+  if (!ctx || !buf || n == 0) return SMN_EINVAL;
+  snprintf(buf, n, "%s", ctx->err.c_str());
+  return SMN_OK;
+}
+
+extern "C" int smn_synchronize(smn_ctx* ctx) {
+  if (!ctx) return SMN_EINVAL;
+  SMN_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SMN_OK;
+}
+
+extern "C" int smn_malloc(smn_ctx* ctx, size_t bytes, void** dptr) {
+  if (!ctx || !dptr) return SMN_EINVAL;
+  *dptr = nullptr;
+  if (bytes == 0) bytes = 16;
+  SMN_HIP(ctx, hipMalloc(dptr, bytes));
+  return SMN_OK;
+}
+
+extern "C" int smn_free(smn_ctx* ctx, void* dptr) {
+  if (!ctx) return SMN_EINVAL;
+  if (!dptr) return SMN_OK;
+  SMN_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  SMN_HIP(ctx, hipFree(dptr));
+  return SMN_OK;
+}
+
+extern "C" int smn_memset(smn_ctx* ctx, void* dptr, int value, size_t bytes) {
+  if (!ctx) return SMN_EINVAL;
+  SMN_HIP(ctx, hipMemsetAsync(dptr, value, bytes, ctx->stream));
+  return SMN_OK;
+}
+
+extern "C" int smn_memcpy_h2d(smn_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  if (!ctx) return SMN_EINVAL;
+  SMN_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  SMN_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SMN_OK;
+}
+
+extern "C" int smn_memcpy_d2h(smn_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  if (!ctx) return SMN_EINVAL;
+  SMN_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  SMN_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SMN_OK;
+}
+
+extern "C" int smn_memcpy_d2d(smn_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  if (!ctx) return SMN_EINVAL;
+  SMN_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  return SMN_OK;
+}
+
+extern "C" int smn_memcpy2d_h2d(smn_ctx* ctx, void* dst, size_t dpitch, const void* src, size_t spitch,
+                                size_t width_bytes, size_t rows) {
+  if (!ctx) return SMN_EINVAL;
+  SMN_HIP(ctx, hipMemcpy2DAsync(dst, dpitch, src, spitch, width_bytes, rows, hipMemcpyHostToDevice, ctx->stream));
+  SMN_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SMN_OK;
+}
+
+extern "C" int smn_memcpy2d_d2h(smn_ctx* ctx, void* dst, size_t dpitch, const void* src, size_t spitch,
+                                size_t width_bytes, size_t rows) {
+  if (!ctx) return SMN_EINVAL;
+  SMN_HIP(ctx, hipMemcpy2DAsync(dst, dpitch, src, spitch, width_bytes, rows, hipMemcpyDeviceToHost, ctx->stream));
+  SMN_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SMN_OK;
+}
+
+extern "C" int smn_timer_start(smn_ctx* ctx) {
+  if (!ctx) return SMN_EINVAL;
+  SMN_HIP(ctx, hipEventRecord(ctx->ev_t0, ctx->stream));
+  return SMN_OK;
+}
+
+extern "C" int smn_timer_stop_ms(smn_ctx* ctx, double* ms) {
+  if (!ctx || !ms) return SMN_EINVAL;
+  SMN_HIP(ctx, hipEventRecord(ctx->ev_t1, ctx->stream));
+  SMN_HIP(ctx, hipEventSynchronize(ctx->ev_t1));
+  float f = 0.f;
+  SMN_HIP(ctx, hipEventElapsedTime(&f, ctx->ev_t0, ctx->ev_t1));
+  *ms = (double)f;
+  return SMN_OK;
+}

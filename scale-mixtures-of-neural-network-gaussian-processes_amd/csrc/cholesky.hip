@@ -1,0 +1,324 @@
+// cholesky.hip — jittered blocked Cholesky carried through appended rows (partial factorisation).
+//
+// Replaces lax.linalg.cholesky + triangular_solve (spax/utils.py:179-180), the Cholesky inside
+// jax.scipy.stats.multivariate_normal.logpdf (spax/likelihoods.py:27) and the cho_factor /
+// cho_solve pair of neural_tangents' gradient_descent_mse_ensemble (spax/kernels.py:29-32).
+//
+// One engine serves all of them: factor the first n_factor columns of a symmetric matrix whose
+// trailing rows hold right-hand sides (y^T, K_td).  On exit those rows hold B L^-T, and the
+// trailing block holds the Schur complement C - B A^-1 B^T: predictive covariance, -mean and
+// -y^T K^-1 y drop out of the same trailing update that the factorisation needs anyway, so the
+// path has no separate triangular-solve kernels.
+//
+// Right-looking, two levels:  outer panels of 256 columns, inner 128-column sub-panels.
+//   panel_kernel   one workgroup per block of rows below the diagonal block; every workgroup
+//                  re-factors the 128x128 diagonal block in LDS (unblocked, right-looking) and
+//                  carries its own rows through the same column operations (a true TRSM, no
+//                  explicit inverse).  Workgroup 0 stores L_kk, sum(log pivots) and the info flag.
+//   update_kernel  C -= A B^T on the f32/f64 MFMA (gemm_nt.hpp): the 128-wide strip update in
+//                  front of the second sub-panel (K=128) and the trailing update (K=256, lower
+//                  tiles only), where nearly all the N^3/3 flops are.
+#include <climits>
+
+#include "gemm_nt.hpp"
+#include "internal.hpp"
+
+namespace {
+
+constexpr int PB = 128;  // sub-panel width == diagonal block edge == GEMM tile edge
+
+template <typename T>
+struct PanelCfg;
+template <>
+struct PanelCfg<float> {
+  static constexpr int XR = 128;       // appended rows per workgroup
+  static constexpr int THREADS = 256;  // one thread per LDS row
+};
+template <>
+struct PanelCfg<double> {
+  static constexpr int XR = 16;        // 128x129 f64 diagonal block already takes 132 KB of LDS
+  static constexpr int THREADS = 192;
+};
+
+__device__ __forceinline__ float rsqrt_t(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ double rsqrt_t(double x) { return 1.0 / sqrt(x); }
+
+// a: matrix base, j0: first column of the sub-panel, rows [j0, j0+128) are the diagonal block,
+// row blocks of XR rows follow from `rbeg` (== j0 + 128) up to n_total.
+// prefactored != 0: the diagonal block already holds L (solve only; used by smn_trsm).
+template <typename T>
+__global__ void __launch_bounds__(PanelCfg<T>::THREADS) panel_kernel(T* __restrict__ a, int64_t lda, int64_t j0,
+                                                                     int64_t rbeg, int64_t n_total, int prefactored,
+                                                                     double* __restrict__ logdet,
+                                                                     int* __restrict__ info) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int XR = PanelCfg<T>::XR, NT = PanelCfg<T>::THREADS, LD = PB + 1;
+  T* S = reinterpret_cast<T*>(smem);  // [PB + XR][LD]
+  const int tid = threadIdx.x;
+  const int64_t rb = rbeg + (int64_t)blockIdx.x * XR;  // first appended row of this workgroup
+  const int nx = (int)max((int64_t)0, min((int64_t)XR, n_total - rb));
+  for (int idx = tid; idx < PB * PB; idx += NT) {
+    const int r = idx / PB, c = idx % PB;
+    S[r * LD + c] = a[(j0 + r) * lda + j0 + c];
+  }
+  for (int idx = tid; idx < nx * PB; idx += NT) {
+    const int r = idx / PB, c = idx % PB;
+    S[(PB + r) * LD + c] = a[(rb + r) * lda + j0 + c];
+  }
+  __syncthreads();
+
+  const int row = tid;
+  const bool active = row < PB + nx;
+  const bool is_diag_row = row < PB;
+  int bad = INT_MAX;
+  for (int j = 0; j < PB; ++j) {
+    const T d = S[j * LD + j];
+    T rinv;
+    if (prefactored) {
+      rinv = T(1) / d;
+    } else {
+      if (!(d > T(0)) && bad == INT_MAX) bad = j;
+      rinv = rsqrt_t(d);
+    }
+    T l = T(0);
+    const bool mine = active && row > j && !(prefactored && is_diag_row);
+    if (mine) {
+      l = S[row * LD + j] * rinv;
+      S[row * LD + j] = l;
+    }
+    __syncthreads();
+    if (mine) {
+      const int cmax = is_diag_row ? row : PB - 1;
+      for (int c = j + 1; c <= cmax; ++c) S[row * LD + c] = fma(-l, S[c * LD + j], S[row * LD + c]);
+    }
+    __syncthreads();
+  }
+
+  if (blockIdx.x == 0 && !prefactored) {
+    // diagonal entries still hold the pivots d_j = L_jj^2
+    double lg = 0.0;
+    if (tid < PB) {
+      const T d = S[tid * LD + tid];
+      lg = log((double)d);
+    }
+    __syncthreads();
+    if (tid < PB) S[tid * LD + tid] = sqrt(S[tid * LD + tid]);
+    // block reduce lg over the first PB threads (NT >= PB, multiple of 64)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) lg += __shfl_xor(lg, o);
+    __shared__ double red[4];
+    if ((tid & 63) == 0 && tid < 256) red[tid >> 6] = lg;
+    __syncthreads();
+    if (tid == 0) {
+      double s = red[0] + red[1];  // PB = 128 -> waves 0 and 1 hold the pivots
+      atomicAdd(logdet, s);
+      if (bad != INT_MAX) atomicMin(info, (int)(j0 + bad + 1));
+    }
+    for (int idx = tid; idx < PB * PB; idx += NT) {
+      const int r = idx / PB, c = idx % PB;
+      if (c <= r) a[(j0 + r) * lda + j0 + c] = S[r * LD + c];
+    }
+  }
+  for (int idx = tid; idx < nx * PB; idx += NT) {
+    const int r = idx / PB, c = idx % PB;
+    a[(rb + r) * lda + j0 + c] = S[(PB + r) * LD + c];
+  }
+}
+
+// C[r0 + ., c0 + .] -= A_rows * B_rows^T over K columns starting at column k0 of the same matrix.
+//   A_rows = a[r0 + tile_r*128 ..., k0 : k0+K],  B_rows = a[c0 + tile_c*128 ..., k0 : k0+K]
+// lower != 0: triangular tile enumeration (tc <= tr), requires r0 == c0.
+template <typename T>
+struct UpdArgs {
+  T* a; int64_t lda; int64_t r0, c0, k0; int K; int tiles_n; int lower;
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256, sizeof(T) == 8 ? 1 : 2) update_kernel(UpdArgs<T> u) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using Tile = TileNT<T, kTile, kTile>;
+  using M = typename Tile::M;
+  int tr, tc;
+  if (u.lower) {
+    tri_decode(blockIdx.x, tr, tc);
+  } else {
+    tr = blockIdx.x / u.tiles_n;
+    tc = blockIdx.x % u.tiles_n;
+  }
+  const int64_t row0 = u.r0 + (int64_t)tr * kTile, col0 = u.c0 + (int64_t)tc * kTile;
+  Tile t;
+  t.zero();
+  t.mainloop(u.a + row0 * u.lda + u.k0, u.lda, u.a + col0 * u.lda + u.k0, u.lda, u.K, smem);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+#pragma unroll
+  for (int m = 0; m < Tile::MT; ++m)
+#pragma unroll
+    for (int n = 0; n < Tile::NT; ++n)
+#pragma unroll
+      for (int i = 0; i < M::ACC; ++i) {
+        const int64_t gr = row0 + wr * Tile::WM + m * M::TM + M::acc_row(lane, i);
+        const int64_t gc = col0 + wc * Tile::WN + n * M::TN + M::acc_col(lane);
+        T* p = u.a + gr * u.lda + gc;
+        *p = *p - t.acc[m][n][i];
+      }
+}
+
+template <typename T>
+__global__ void diag_trace_kernel(const T* __restrict__ a, int64_t lda, int64_t n, double* __restrict__ out) {
+  // single block; deterministic tree
+  __shared__ double red[256];
+  double s = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += 256) s += (double)a[i * lda + i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *out = red[0];
+}
+
+template <typename T>
+__global__ void diag_shift_kernel(T* __restrict__ a, int64_t lda, int64_t n, double jitter_abs, double ridge_rel,
+                                  const double* __restrict__ trace) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double sh = jitter_abs + (ridge_rel != 0.0 ? ridge_rel * (*trace) / (double)n : 0.0);
+  a[i * lda + i] = (T)((double)a[i * lda + i] + sh);
+}
+
+__global__ void init_scalars_kernel(double* logdet, int* info) {
+  *logdet = 0.0;
+  *info = INT_MAX;
+}
+
+template <typename T>
+int launch_update(smn_ctx* ctx, hipStream_t st, T* a, int64_t lda, int64_t r0, int64_t c0, int64_t k0, int K,
+                  int64_t tiles_m, int64_t tiles_n, int lower) {
+  if (tiles_m <= 0 || tiles_n <= 0 || K <= 0) return SMN_OK;
+  UpdArgs<T> u{a, lda, r0, c0, k0, K, (int)tiles_n, lower};
+  const int64_t nt = lower ? tiles_m * (tiles_m + 1) / 2 : tiles_m * tiles_n;
+  auto kern = update_kernel<T>;
+  const size_t lds = TileNT<T, kTile, kTile>::LDS_BYTES;
+  hipLaunchKernelGGL(kern, dim3((unsigned)nt), dim3(256), lds, st, u);
+  SMN_CHECK_LAUNCH(ctx);
+  return SMN_OK;
+}
+
+template <typename T>
+int launch_panel(smn_ctx* ctx, hipStream_t st, T* a, int64_t lda, int64_t j0, int64_t n_total, int prefactored) {
+  constexpr int XR = PanelCfg<T>::XR;
+  const int64_t rbeg = j0 + PB;
+  const int64_t below = n_total - rbeg;
+  const unsigned grid = below > 0 ? (unsigned)((below + XR - 1) / XR) : 1u;
+  const size_t lds = sizeof(T) * (size_t)(PB + XR) * (PB + 1);
+  auto kern = panel_kernel<T>;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(PanelCfg<T>::THREADS), lds, st, a, lda, j0, rbeg, n_total, prefactored,
+                     ctx->d_scal, ctx->d_info);
+  SMN_CHECK_LAUNCH(ctx);
+  return SMN_OK;
+}
+
+template <typename T>
+int set_lds_attrs(smn_ctx* ctx) {
+  static bool done = false;   // per dtype instantiation
+  if (done) return SMN_OK;
+  SMN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(panel_kernel<T>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)(sizeof(T) * (PB + PanelCfg<T>::XR) * (PB + 1))));
+  SMN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(update_kernel<T>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)TileNT<T, kTile, kTile>::LDS_BYTES));
+  done = true;
+  return SMN_OK;
+}
+
+template <typename T>
+int cholesky_t(smn_ctx* ctx, T* a, int64_t n_total, int64_t n_factor, int64_t lda, int64_t n_shift, double jitter_abs,
+               double ridge_rel) {
+  SMN_TRY(set_lds_attrs<T>(ctx));
+  hipStream_t st = ctx->stream;
+  hipLaunchKernelGGL(init_scalars_kernel, dim3(1), dim3(1), 0, st, ctx->d_scal, ctx->d_info);
+  if (n_shift > 0 && (jitter_abs != 0.0 || ridge_rel != 0.0)) {
+    if (ridge_rel != 0.0)
+      hipLaunchKernelGGL(diag_trace_kernel<T>, dim3(1), dim3(256), 0, st, a, lda, n_shift, ctx->d_scal + 1);
+    hipLaunchKernelGGL(diag_shift_kernel<T>, dim3((unsigned)((n_shift + 255) / 256)), dim3(256), 0, st, a, lda,
+                       n_shift, jitter_abs, ridge_rel, ctx->d_scal + 1);
+  }
+  SMN_CHECK_LAUNCH(ctx);
+  constexpr int64_t W = 2 * PB;
+  for (int64_t j0 = 0; j0 < n_factor; j0 += W) {
+    const int64_t w = (n_factor - j0 < W) ? n_factor - j0 : W;
+    for (int64_t js = j0; js < j0 + w; js += PB) {
+      if (js > j0)  // bring the next sub-panel's column strip up to date: K = js - j0
+        SMN_TRY(launch_update<T>(ctx, st, a, lda, js, js, j0, (int)(js - j0), (n_total - js) / kTile, 1, 0));
+      SMN_TRY(launch_panel<T>(ctx, st, a, lda, js, n_total, 0));
+    }
+    const int64_t j1 = j0 + w;
+    if (j1 < n_total)
+      SMN_TRY(launch_update<T>(ctx, st, a, lda, j1, j1, j0, (int)w, (n_total - j1) / kTile, (n_total - j1) / kTile, 1));
+  }
+  return SMN_OK;
+}
+
+}  // namespace
+
+int cholesky_padded(smn_ctx* ctx, int dtype, void* a, int64_t n_total, int64_t n_factor, int64_t lda, int64_t n_shift,
+                    double jitter_abs, double ridge_rel) {
+  if (n_total % kTile || n_factor % kTile || n_factor > n_total || n_factor <= 0)
+    return smn_fail(ctx, SMN_EINVAL, "cholesky_padded: n_total=%lld n_factor=%lld must be multiples of %d",
+                    (long long)n_total, (long long)n_factor, kTile);
+  if (lda % (16 / (int)dtype_size(dtype)) || (reinterpret_cast<uintptr_t>(a) & 15))
+    return smn_fail(ctx, SMN_EINVAL, "cholesky_padded: matrix must be 16-byte aligned");
+  if (dtype == SMN_F64)
+    return cholesky_t<double>(ctx, static_cast<double*>(a), n_total, n_factor, lda, n_shift, jitter_abs, ridge_rel);
+  return cholesky_t<float>(ctx, static_cast<float*>(a), n_total, n_factor, lda, n_shift, jitter_abs, ridge_rel);
+}
+
+// Solve-only sweep: rows [n_factor, n_total) of `a` <- rows * L^-T with L = the (already factored)
+// leading block.  Left-looking over block columns; used by smn_trsm.
+int solve_rows_padded(smn_ctx* ctx, int dtype, void* a, int64_t n_total, int64_t n_factor, int64_t lda) {
+  if (n_total % kTile || n_factor % kTile) return smn_fail(ctx, SMN_EINVAL, "solve_rows_padded: padding");
+  hipStream_t st = ctx->stream;
+  for (int64_t js = 0; js < n_factor; js += PB) {
+    if (dtype == SMN_F64) {
+      SMN_TRY(set_lds_attrs<double>(ctx));
+      // appended rows only: C = a[n_factor:, js:js+128] -= a[n_factor:, 0:js] * a[js:js+128, 0:js]^T
+      SMN_TRY(launch_update<double>(ctx, st, static_cast<double*>(a), lda, n_factor, js, 0, (int)js,
+                                    (n_total - n_factor) / kTile, 1, 0));
+    } else {
+      SMN_TRY(set_lds_attrs<float>(ctx));
+      SMN_TRY(launch_update<float>(ctx, st, static_cast<float*>(a), lda, n_factor, js, 0, (int)js,
+                                   (n_total - n_factor) / kTile, 1, 0));
+    }
+    // panel solve against the prefactored diagonal block; row blocks start at n_factor
+    if (dtype == SMN_F64) {
+      constexpr int XR = PanelCfg<double>::XR;
+      const unsigned grid = (unsigned)((n_total - n_factor + XR - 1) / XR);
+      hipLaunchKernelGGL(panel_kernel<double>, dim3(grid), dim3(PanelCfg<double>::THREADS),
+                         sizeof(double) * (size_t)(PB + XR) * (PB + 1), st, static_cast<double*>(a), lda, js, n_factor,
+                         n_total, 1, ctx->d_scal, ctx->d_info);
+    } else {
+      constexpr int XR = PanelCfg<float>::XR;
+      const unsigned grid = (unsigned)((n_total - n_factor + XR - 1) / XR);
+      hipLaunchKernelGGL(panel_kernel<float>, dim3(grid), dim3(PanelCfg<float>::THREADS),
+                         sizeof(float) * (size_t)(PB + XR) * (PB + 1), st, static_cast<float*>(a), lda, js, n_factor,
+                         n_total, 1, ctx->d_scal, ctx->d_info);
+    }
+    SMN_CHECK_LAUNCH(ctx);
+  }
+  return SMN_OK;
+}
+
+int fetch_logdet_info(smn_ctx* ctx, double* logdet, int* info) {
+  double ld = 0.0;
+  int inf = 0;
+  SMN_HIP(ctx, hipMemcpyAsync(&ld, ctx->d_scal, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  SMN_HIP(ctx, hipMemcpyAsync(&inf, ctx->d_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  SMN_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (inf == INT_MAX) inf = 0;
+  if (logdet) *logdet = ld;
+  if (info) *info = inf;
+  return SMN_OK;
+}

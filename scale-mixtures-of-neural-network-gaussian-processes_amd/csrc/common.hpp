@@ -1,0 +1,62 @@
+// common.hpp — context, error plumbing and small helpers shared by every translation unit of
+// libsmnngp.so.  gfx950 only.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/smnngp.h"
+
+struct smn_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;   // main stream: every public call is ordered on it
+  hipStream_t stream2 = nullptr;  // look-ahead stream of the Cholesky driver
+  hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
+  std::string err;
+  // cached workspace arenas (grown on demand, freed with the context)
+  void* ws[4] = {nullptr, nullptr, nullptr, nullptr};
+  size_t ws_bytes[4] = {0, 0, 0, 0};
+  // small device scalar block: [0..15] doubles scratch, ints after
+  double* d_scal = nullptr;   // 64 doubles
+  int* d_info = nullptr;      // 16 ints
+  void* comm = nullptr;       // ncclComm_t when smn_comm_init was called
+  int nranks = 1, rank = 0;
+};
+
+inline int smn_fail(smn_ctx* ctx, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (ctx) ctx->err = buf;
+  return code;
+}
+
+#define SMN_HIP(ctx, call)                                                                   \
+  do {                                                                                       \
+    hipError_t e_ = (call);                                                                  \
+    if (e_ != hipSuccess)                                                                    \
+      return smn_fail((ctx), e_ == hipErrorOutOfMemory ? SMN_ENOMEM : SMN_EHIP, "%s: %s (%s:%d)", \
+                      #call, hipGetErrorString(e_), __FILE__, __LINE__);                     \
+  } while (0)
+
+#define SMN_TRY(expr)         \
+  do {                        \
+    int rc_ = (expr);         \
+    if (rc_ != SMN_OK) return rc_; \
+  } while (0)
+
+#define SMN_CHECK_LAUNCH(ctx) SMN_HIP(ctx, hipGetLastError())
+
+inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+// workspace slot `slot` of at least `bytes` bytes (contents undefined)
+int smn_workspace(smn_ctx* ctx, int slot, size_t bytes, void** out);
+
+inline size_t dtype_size(int dtype) { return dtype == SMN_F64 ? 8 : 4; }

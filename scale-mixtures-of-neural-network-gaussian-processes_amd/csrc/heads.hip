@@ -1,0 +1,231 @@
+// heads.hip — the inference heads of the path, all expressed on ONE augmented matrix:
+//
+//        [ K + shift   .          .   ]   rows 0 .. n_pad        (training block, identity padding)
+//   A =  [ K_td        K_tt       .   ]   rows n_pad .. +t       (test rows)
+//        [ y^T         0          0   ]   rows n_pad+t .. +c     (one row per output column of y)
+//
+// A partial Cholesky over the first n_pad columns (cholesky.hip) leaves
+//   rows t:  K_td L^-T            Schur(t,t)  = K_tt - K_td K~^-1 K_dt      -> predictive covariance
+//   rows y:  z^T = (L^-1 y)^T     Schur(y,t)  = - y^T K~^-1 K_dt            -> -predictive mean
+//                                 Schur(y,y)  = - y^T K~^-1 y               -> -quadratic form
+// and sum(log pivots) = logdet.  That covers
+//   SPR.loss                      spax/models.py:93-98   (+ likelihoods.py:25-28,45-50, utils.py:160-183)
+//   NNGPKernel.predict            spax/kernels.py:29-32  (neural_tangents gradient_descent_mse_ensemble)
+//   the quadratic form of StudentTLikelihood.logpdf      spax/likelihoods.py:60-61
+// The closed-form log-pdf arithmetic on the resulting scalars is done on the host (lgamma etc.).
+#include <cmath>
+
+#include "internal.hpp"
+
+namespace {
+
+struct Aug {
+  int64_t n, n_pad, t, c, n_total, lda;
+  void* a;
+  size_t es;
+  char* at(int64_t r, int64_t col) const { return static_cast<char*>(a) + es * (size_t)(r * lda + col); }
+};
+
+int aug_alloc(smn_ctx* ctx, int dtype, int64_t n, int64_t t, int64_t c, Aug* g) {
+  g->n = n; g->t = t; g->c = c;
+  g->n_pad = round_up(n, kTile);
+  g->n_total = g->n_pad + round_up(t + c, kTile);
+  g->lda = g->n_total;
+  g->es = dtype_size(dtype);
+  return smn_workspace(ctx, 2, g->es * (size_t)g->n_total * (size_t)g->n_total, &g->a);
+}
+
+int fetch_doubles(smn_ctx* ctx, const double* dev, double* host, int n) {
+  SMN_HIP(ctx, hipMemcpyAsync(host, dev, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
+  SMN_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SMN_OK;
+}
+
+// Gaussian / multivariate-t log-pdf from (quad = y^T cov^-1 y, logdet = log det cov).
+double logpdf_from(double quad, double logdet, int64_t n, double df, double scale, int info) {
+  if (info != 0 || std::isnan(quad) || std::isnan(logdet)) return std::nan("");
+  const double nn = (double)n;
+  if (df <= 0.0)  // jax.scipy.stats.multivariate_normal.logpdf, spax/likelihoods.py:27
+    return -0.5 * quad - 0.5 * nn * std::log(2.0 * M_PI) - 0.5 * logdet;
+  // spax/utils.py:178-183 with shape = scale * cov
+  const double t = 0.5 * (df + nn);
+  const double quad_s = quad / scale;
+  const double logdet_s = logdet + nn * std::log(scale);
+  return -t * std::log1p(quad_s / df) - 0.5 * nn * std::log(df * M_PI) + std::lgamma(t) - std::lgamma(0.5 * df) -
+         0.5 * logdet_s;
+}
+
+// Fused build of the augmented matrix straight from the inputs.
+int aug_build(smn_ctx* ctx, const BuildSpec& spec, const Aug& g, const void* x, int64_t ldx, const void* xt,
+              int64_t ldxt, int64_t d) {
+  const int64_t kp = k_pad(spec.dtype, d);
+  void* xs = nullptr;
+  SMN_TRY(smn_workspace(ctx, 0, g.es * (size_t)kp * (size_t)g.n_total + sizeof(double) * (size_t)g.n_total, &xs));
+  double* q = static_cast<double*>(xs);
+  char* xp = reinterpret_cast<char*>(q + g.n_total);
+  SMN_TRY(pad_rows(ctx, spec.dtype, x, g.n, ldx, d, xp, g.n_pad, kp, q));
+  SMN_TRY(pad_rows(ctx, spec.dtype, xt, g.t, ldxt, d, xp + g.es * (size_t)kp * (size_t)g.n_pad, g.n_total - g.n_pad, kp,
+                   q + g.n_pad));
+  BuildCall c{};
+  c.spec = spec;
+  c.x1p = xp; c.ld1 = kp; c.rows1 = g.n_total; c.q1 = q;
+  c.x2p = xp; c.ld2 = kp; c.rows2 = g.n_total; c.q2 = q;
+  c.kp = (int)kp; c.d = d;
+  c.symmetric = 1; c.mirror = 0; c.exact_diag = 1;
+  c.store_mode = STORE_PAD_IDENTITY;
+  c.nv0 = g.n; c.aug0 = g.n_pad; c.nv1 = g.t;
+  c.get_mask = SMN_GET_NNGP;
+  c.out_k = g.a; c.ldo = g.lda;
+  return run_build(ctx, c);
+}
+
+int aug_finish(smn_ctx* ctx, int dtype, const Aug& g, const void* y, int64_t ldy, int64_t n_shift, double jitter_abs,
+               double ridge_rel, void* mean, void* cov, int64_t ldcov, double* quad_h, double* logdet_h, int* info_h) {
+  SMN_TRY(set_aug_rows(ctx, dtype, g.a, g.lda, g.n_pad + g.t, g.n_total, y, g.n, g.c, ldy));
+  SMN_TRY(cholesky_padded(ctx, dtype, g.a, g.n_total, g.n_pad, g.lda, n_shift, jitter_abs, ridge_rel));
+  double* quad_dev = ctx->d_scal + 8;
+  if (g.c > 48) return smn_fail(ctx, SMN_ENOTSUP, "more than 48 output columns");
+  SMN_TRY(extract_posterior(ctx, dtype, g.a, g.lda, g.n_pad, g.t, g.c, mean, cov, ldcov, quad_dev));
+  double ld = 0.0;
+  int info = 0;
+  SMN_TRY(fetch_logdet_info(ctx, &ld, &info));
+  if (quad_h) SMN_TRY(fetch_doubles(ctx, quad_dev, quad_h, (int)g.c));
+  if (info != 0) {
+    ld = std::nan("");
+    if (quad_h)
+      for (int64_t k = 0; k < g.c; ++k) quad_h[k] = std::nan("");
+  }
+  if (logdet_h) *logdet_h = ld;
+  if (info_h) *info_h = info;
+  return SMN_OK;
+}
+
+}  // namespace
+
+extern "C" int smn_cholesky(smn_ctx* ctx, int dtype, void* a_d, int64_t n_total, int64_t n_factor, int64_t lda,
+                            int64_t n_shift, double jitter_abs, double ridge_rel, int* info_h, double* logdet_h) {
+  if (!ctx || !a_d) return SMN_EINVAL;
+  if (dtype != SMN_F32 && dtype != SMN_F64) return smn_fail(ctx, SMN_EINVAL, "bad dtype");
+  if (n_factor <= 0 || n_factor > n_total || lda < n_total || n_shift < 0 || n_shift > n_factor)
+    return smn_fail(ctx, SMN_EINVAL, "smn_cholesky: bad sizes");
+  const size_t es = dtype_size(dtype);
+  const bool inplace = n_total % kTile == 0 && n_factor % kTile == 0 && lda % (16 / (int64_t)es) == 0 &&
+                       (reinterpret_cast<uintptr_t>(a_d) & 15) == 0;
+  if (inplace) {
+    SMN_TRY(cholesky_padded(ctx, dtype, a_d, n_total, n_factor, lda, n_shift, jitter_abs, ridge_rel));
+  } else {
+    const int64_t m = n_total - n_factor, nfp = round_up(n_factor, kTile), ntp = nfp + round_up(m, kTile);
+    void* w = nullptr;
+    SMN_TRY(smn_workspace(ctx, 2, es * (size_t)ntp * (size_t)ntp, &w));
+    char* wb = static_cast<char*>(w);
+    const char* ab = static_cast<const char*>(a_d);
+    SMN_HIP(ctx, hipMemsetAsync(w, 0, es * (size_t)ntp * (size_t)ntp, ctx->stream));
+    SMN_TRY(copy_matrix(ctx, dtype, wb, ntp, ab, lda, n_factor, n_factor, 1));
+    SMN_TRY(copy_matrix(ctx, dtype, wb + es * (size_t)(nfp * ntp), ntp, ab + es * (size_t)(n_factor * lda), lda, m, n_factor, 0));
+    SMN_TRY(copy_matrix(ctx, dtype, wb + es * (size_t)(nfp * ntp + nfp), ntp, ab + es * (size_t)(n_factor * lda + n_factor), lda, m, m, 1));
+    SMN_TRY(fill_identity_pad(ctx, dtype, w, ntp, nfp, n_factor));
+    SMN_TRY(cholesky_padded(ctx, dtype, w, ntp, nfp, ntp, n_shift, jitter_abs, ridge_rel));
+    char* ao = static_cast<char*>(a_d);
+    SMN_TRY(copy_matrix(ctx, dtype, ao, lda, wb, ntp, n_factor, n_factor, 1));
+    SMN_TRY(copy_matrix(ctx, dtype, ao + es * (size_t)(n_factor * lda), lda, wb + es * (size_t)(nfp * ntp), ntp, m, n_factor, 0));
+    SMN_TRY(copy_matrix(ctx, dtype, ao + es * (size_t)(n_factor * lda + n_factor), lda, wb + es * (size_t)(nfp * ntp + nfp), ntp, m, m, 1));
+  }
+  double ld = 0.0;
+  int info = 0;
+  SMN_TRY(fetch_logdet_info(ctx, &ld, &info));
+  if (info != 0) ld = std::nan("");
+  if (logdet_h) *logdet_h = ld;
+  if (info_h) *info_h = info;
+  return SMN_OK;
+}
+
+extern "C" int smn_trsm(smn_ctx* ctx, int dtype, const void* l_d, int64_t n, int64_t ldl, void* b_d, int64_t nrhs,
+                        int64_t ldb, int trans) {
+  if (!ctx || !l_d || !b_d) return SMN_EINVAL;
+  if (dtype != SMN_F32 && dtype != SMN_F64) return smn_fail(ctx, SMN_EINVAL, "bad dtype");
+  if (n <= 0 || nrhs <= 0) return smn_fail(ctx, SMN_EINVAL, "smn_trsm: empty");
+  if (trans != 0) return smn_fail(ctx, SMN_ENOTSUP, "smn_trsm: trans=1 (L^T) is not implemented yet");
+  Aug g;
+  SMN_TRY(aug_alloc(ctx, dtype, n, nrhs, 0, &g));
+  SMN_HIP(ctx, hipMemsetAsync(g.a, 0, g.es * (size_t)g.n_total * (size_t)g.n_total, ctx->stream));
+  SMN_TRY(copy_matrix(ctx, dtype, g.a, g.lda, l_d, ldl, n, n, 1));
+  SMN_TRY(fill_identity_pad(ctx, dtype, g.a, g.lda, g.n_pad, n));
+  SMN_TRY(transpose_matrix(ctx, dtype, g.at(g.n_pad, 0), g.lda, b_d, ldb, n, nrhs));
+  SMN_TRY(solve_rows_padded(ctx, dtype, g.a, g.n_total, g.n_pad, g.lda));
+  SMN_TRY(transpose_matrix(ctx, dtype, b_d, ldb, g.at(g.n_pad, 0), g.lda, nrhs, n));
+  return SMN_OK;
+}
+
+extern "C" int smn_lml(smn_ctx* ctx, int dtype, void* k_d, int64_t n, int64_t ldk, const void* y_d, double eps_abs,
+                       double df, double scale, double* logpdf_h, double* quad_h, double* logdet_h, int* info_h) {
+  if (!ctx || !k_d || !y_d) return SMN_EINVAL;
+  if (dtype != SMN_F32 && dtype != SMN_F64) return smn_fail(ctx, SMN_EINVAL, "bad dtype");
+  if (n <= 0) return smn_fail(ctx, SMN_EINVAL, "smn_lml: empty");
+  if (df > 0.0 && !(scale > 0.0)) return smn_fail(ctx, SMN_EINVAL, "smn_lml: scale must be > 0");
+  Aug g;
+  SMN_TRY(aug_alloc(ctx, dtype, n, 0, 1, &g));
+  SMN_HIP(ctx, hipMemsetAsync(g.a, 0, g.es * (size_t)g.n_total * (size_t)g.n_total, ctx->stream));
+  SMN_TRY(copy_matrix(ctx, dtype, g.a, g.lda, k_d, ldk, n, n, 1));
+  SMN_TRY(fill_identity_pad(ctx, dtype, g.a, g.lda, g.n_pad, n));
+  double quad = 0.0, ld = 0.0;
+  int info = 0;
+  SMN_TRY(aug_finish(ctx, dtype, g, y_d, 1, n, eps_abs, 0.0, nullptr, nullptr, 0, &quad, &ld, &info));
+  if (logpdf_h) *logpdf_h = logpdf_from(quad, ld, n, df, scale, info);
+  if (quad_h) *quad_h = quad;
+  if (logdet_h) *logdet_h = ld;
+  if (info_h) *info_h = info;
+  return SMN_OK;
+}
+
+extern "C" int smn_predict(smn_ctx* ctx, int dtype, void* kj_d, int64_t n, int64_t t, int64_t ldk, const void* y_d,
+                           int64_t c, double ridge_rel, double ridge_abs, void* mean_d, void* cov_d, int64_t ldcov,
+                           double* quad_h, double* logdet_h, int* info_h) {
+  if (!ctx || !kj_d || !y_d) return SMN_EINVAL;
+  if (dtype != SMN_F32 && dtype != SMN_F64) return smn_fail(ctx, SMN_EINVAL, "bad dtype");
+  if (n <= 0 || t < 0 || c <= 0) return smn_fail(ctx, SMN_EINVAL, "smn_predict: bad sizes");
+  Aug g;
+  SMN_TRY(aug_alloc(ctx, dtype, n, t, c, &g));
+  const char* kb = static_cast<const char*>(kj_d);
+  SMN_HIP(ctx, hipMemsetAsync(g.a, 0, g.es * (size_t)g.n_total * (size_t)g.n_total, ctx->stream));
+  SMN_TRY(copy_matrix(ctx, dtype, g.a, g.lda, kb, ldk, n, n, 1));
+  SMN_TRY(copy_matrix(ctx, dtype, g.at(g.n_pad, 0), g.lda, kb + g.es * (size_t)(n * ldk), ldk, t, n, 0));
+  SMN_TRY(copy_matrix(ctx, dtype, g.at(g.n_pad, g.n_pad), g.lda, kb + g.es * (size_t)(n * ldk + n), ldk, t, t, 1));
+  SMN_TRY(fill_identity_pad(ctx, dtype, g.a, g.lda, g.n_pad, n));
+  return aug_finish(ctx, dtype, g, y_d, c, n, ridge_abs, ridge_rel, mean_d, cov_d, ldcov, quad_h, logdet_h, info_h);
+}
+
+extern "C" int smn_spr_loss(smn_ctx* ctx, int dtype, int net, int act, int num_hiddens, double w_std, double b_std,
+                            double last_w_std, const void* x_d, int64_t n, int64_t ldx, int64_t d, const void* y_d,
+                            double eps_abs, double df, double scale, double* logpdf_h, double* quad_h, double* logdet_h,
+                            int* info_h) {
+  if (!ctx || !x_d || !y_d) return SMN_EINVAL;
+  if (dtype != SMN_F32 && dtype != SMN_F64) return smn_fail(ctx, SMN_EINVAL, "bad dtype");
+  if (n <= 0 || d <= 0) return smn_fail(ctx, SMN_EINVAL, "smn_spr_loss: empty");
+  if (df > 0.0 && !(scale > 0.0)) return smn_fail(ctx, SMN_EINVAL, "smn_spr_loss: scale must be > 0");
+  Aug g;
+  SMN_TRY(aug_alloc(ctx, dtype, n, 0, 1, &g));
+  BuildSpec s{dtype, net, act, num_hiddens, w_std, b_std, last_w_std};
+  SMN_TRY(aug_build(ctx, s, g, x_d, ldx, x_d, ldx, d));
+  double quad = 0.0, ld = 0.0;
+  int info = 0;
+  SMN_TRY(aug_finish(ctx, dtype, g, y_d, 1, n, eps_abs, 0.0, nullptr, nullptr, 0, &quad, &ld, &info));
+  if (logpdf_h) *logpdf_h = logpdf_from(quad, ld, n, df, scale, info);
+  if (quad_h) *quad_h = quad;
+  if (logdet_h) *logdet_h = ld;
+  if (info_h) *info_h = info;
+  return SMN_OK;
+}
+
+extern "C" int smn_spr_predict(smn_ctx* ctx, int dtype, int net, int act, int num_hiddens, double w_std, double b_std,
+                               double last_w_std, const void* x_d, int64_t n, int64_t ldx, const void* xt_d, int64_t t,
+                               int64_t ldxt, int64_t d, const void* y_d, int64_t c, double ridge_rel, double ridge_abs,
+                               void* mean_d, void* cov_d, int64_t ldcov, double* quad_h, double* logdet_h, int* info_h) {
+  if (!ctx || !x_d || !y_d || (t > 0 && !xt_d)) return SMN_EINVAL;
+  if (dtype != SMN_F32 && dtype != SMN_F64) return smn_fail(ctx, SMN_EINVAL, "bad dtype");
+  if (n <= 0 || d <= 0 || t < 0 || c <= 0) return smn_fail(ctx, SMN_EINVAL, "smn_spr_predict: bad sizes");
+  Aug g;
+  SMN_TRY(aug_alloc(ctx, dtype, n, t, c, &g));
+  BuildSpec s{dtype, net, act, num_hiddens, w_std, b_std, last_w_std};
+  SMN_TRY(aug_build(ctx, s, g, x_d, ldx, t > 0 ? xt_d : x_d, t > 0 ? ldxt : ldx, d));
+  return aug_finish(ctx, dtype, g, y_d, c, n, ridge_abs, ridge_rel, mean_d, cov_d, ldcov, quad_h, logdet_h, info_h);
+}

@@ -1,0 +1,58 @@
+// internal.hpp — C++-side interfaces between the translation units of libsmnngp.so.
+#pragma once
+#include "common.hpp"
+
+constexpr int kTile = 128;   // GEMM block edge; every padded dimension is a multiple of it
+
+struct BuildSpec {
+  int dtype, net, act, num_hiddens;
+  double w_std, b_std, last_w_std;
+};
+
+enum { STORE_BOUNDS = 0, STORE_PAD_IDENTITY = 1 };
+
+// One fused Gram + layer-recursion launch.  Operands are PADDED copies (rows a multiple of 128,
+// K a multiple of 32 elements, zero filled) made by pad_rows(); q1/q2 are ||x||^2/d per padded row.
+struct BuildCall {
+  BuildSpec spec;
+  const void* x1p; int64_t ld1; int64_t rows1;
+  const void* x2p; int64_t ld2; int64_t rows2;
+  int kp; int64_t d;
+  const double* q1; const double* q2;
+  int symmetric;               // 1: x2 == x1, only tiles with tc <= tr are computed
+  int mirror;                  // symmetric only: also store the transposed tile (full matrix out)
+  int64_t row_off, col_off;    // added to local indices for the row == col (exact diagonal) test
+  int exact_diag;              // write the closed-form diagonal where global row == global col
+  int store_mode;              // STORE_BOUNDS: write [0,out_rows) x [0,out_cols) only
+  int64_t out_rows, out_cols;  // STORE_PAD_IDENTITY: write everything, identity outside `valid`
+  int64_t nv0, aug0, nv1;      // valid(i) = i < nv0 || (aug0 <= i < aug0 + nv1)
+  int get_mask;
+  void* out_k; void* out_t; int64_t ldo;
+};
+int run_build(smn_ctx* ctx, const BuildCall& c);
+
+// dst[rows_pad, kp] (ld = kp) <- zero-padded copy of src[n, d]; also q[rows_pad] = ||row||^2 / d.
+int pad_rows(smn_ctx* ctx, int dtype, const void* src, int64_t n, int64_t lds, int64_t d,
+             void* dst, int64_t rows_pad, int64_t kp, double* q);
+
+inline int64_t k_pad(int dtype, int64_t d) { return round_up(d, dtype == SMN_F64 ? 16 : 32); }
+
+// Partial Cholesky on a padded matrix (n_total, n_factor multiples of 128).  Device-side results:
+// logdet (double) and info (int) are left in ctx->d_scal[0] / ctx->d_info[0]; no host sync.
+int cholesky_padded(smn_ctx* ctx, int dtype, void* a, int64_t n_total, int64_t n_factor, int64_t lda,
+                    int64_t n_shift, double jitter_abs, double ridge_rel);
+int fetch_logdet_info(smn_ctx* ctx, double* logdet, int* info);
+
+// small helpers implemented in util.hip
+int fill_identity_pad(smn_ctx* ctx, int dtype, void* a, int64_t lda, int64_t n_pad, int64_t n_valid);
+int copy_matrix(smn_ctx* ctx, int dtype, void* dst, int64_t ldd, const void* src, int64_t lds,
+                int64_t rows, int64_t cols, int lower_only);
+// a[row0 + k, i] = (i < n ? y[i*ldy + k] : 0) for k < c, i < ncols   (whole rows are written)
+int set_aug_rows(smn_ctx* ctx, int dtype, void* a, int64_t lda, int64_t row0, int64_t ncols, const void* y,
+                 int64_t n, int64_t c, int64_t ldy);
+// predictive read-out of a factored augmented matrix (see heads.hip)
+int extract_posterior(smn_ctx* ctx, int dtype, const void* a, int64_t lda, int64_t aug0, int64_t t, int64_t c,
+                      void* mean, void* cov, int64_t ldcov, double* quad_dev);
+int solve_rows_padded(smn_ctx* ctx, int dtype, void* a, int64_t n_total, int64_t n_factor, int64_t lda);
+int transpose_matrix(smn_ctx* ctx, int dtype, void* dst, int64_t ldd, const void* src, int64_t lds,
+                     int64_t rows, int64_t cols);   // dst[c, r] = src[r, c]

@@ -1,0 +1,560 @@
+// kernel_build.hip — NNGP / NTK kernel-matrix construction.
+//
+// Replaces kernel_fn(x1, x2, get) of experiments/nt_kernels.py:21-31,83-103 (neural_tangents
+// stax.serial of Dense / Relu / Erf; called at spax/kernels.py:23-27, find.py:64-70):
+//   1. pad_rows:       zero-padded operand copy + q_i = ||x_i||^2 / d          (HBM streaming)
+//   2. diag_tables:    per-row, per-layer factors r, s and the closed-form diagonal (O(N L))
+//   3. build_kernel:   K0 = X1 X2^T / d on the f32/f64 MFMA with the WHOLE layer recursion fused
+//                      into the epilogue, so K0 never exists in HBM
+//   4. recursion_kernel: the same per-element program as an HBM-streaming pass over a stored K0
+//                      (hyper-parameter sweeps that reuse K0; the roofline measurement of a3)
+#include "gemm_nt.hpp"
+#include "internal.hpp"
+#include "layer_prog.hpp"
+
+namespace {
+
+// ------------------------------------------------------------------ prep kernels
+template <typename T>
+__global__ void pad_rows_kernel(const T* __restrict__ src, int64_t n, int64_t lds, int64_t d,
+                                T* __restrict__ dst, int64_t rows_pad, int64_t kp, double inv_d,
+                                double* __restrict__ q) {
+  // one wave per padded row
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows_pad) return;
+  double s = 0.0;
+  for (int64_t c = lane; c < kp; c += 64) {
+    T v = (row < n && c < d) ? src[row * lds + c] : T(0);
+    dst[row * kp + c] = v;
+    s += (double)v * (double)v;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if (lane == 0 && q) q[row] = s * inv_d;
+}
+
+// Per-row tables.  tab[(set*2+0)*ldt + i] = r, tab[(set*2+1)*ldt + i] = s, dg[i] = final diagonal.
+template <typename T>
+__global__ void diag_tables_kernel(const double* __restrict__ q0, int64_t n, LayerProg p,
+                                   T* __restrict__ tab, int64_t ldt, T* __restrict__ dg) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double q = q0[i];
+  if (p.net == NET_RESNET) q = p.w2 * q + p.b2;
+  for (int s = 0; s < p.nsets; ++s) {
+    double qt = (p.net == NET_MLP) ? p.w2 * q + p.b2 : q;   // pre-activation variance
+    double r, sv, qa;
+    if (p.act == ACT_RELU) {
+      r = qt > 0.0 ? 1.0 / sqrt(qt) : 0.0;
+      sv = sqrt(qt / (2.0 * nngp::kPi));
+      qa = 0.5 * qt;
+    } else {
+      r = 1.0 / sqrt(1.0 + 2.0 * qt);
+      sv = 0.0;
+      qa = (2.0 / nngp::kPi) * asin(2.0 * qt / (1.0 + 2.0 * qt));
+    }
+    tab[(int64_t)(2 * s) * ldt + i] = (T)r;
+    tab[(int64_t)(2 * s + 1) * ldt + i] = (T)sv;
+    if (p.net == NET_MLP || s == p.nsets - 1) q = qa;
+    else q = q + p.w2 * qa + p.b2;
+  }
+  if (p.net != NET_NONE) q *= p.lw2;
+  dg[i] = (T)q;
+}
+
+// ------------------------------------------------------------------ fused Gram + recursion
+template <typename T>
+struct BuildArgs {
+  const T* x1; const T* x2; int64_t ld1, ld2; int kp;
+  int tiles_n; int symmetric; int mirror;
+  const T* tab1; const T* tab2; int64_t ldt1, ldt2; const T* dg;
+  T inv_d; LayerProg prog;
+  int64_t row_off, col_off; int exact_diag;
+  int store_mode; int64_t out_rows, out_cols; int64_t nv0, aug0, nv1;
+  T* out_k; T* out_t; int64_t ldo;
+};
+
+template <typename T, int NET, int ACT, bool NTK>
+__global__ void __launch_bounds__(256, (NTK || sizeof(T) == 8) ? 1 : 2) build_kernel(BuildArgs<T> a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using Tile = TileNT<T, kTile, kTile>;
+  using M = typename Tile::M;
+  int tr, tc;
+  if (a.symmetric) {
+    tri_decode(blockIdx.x, tr, tc);
+  } else {
+    tr = blockIdx.x / a.tiles_n;
+    tc = blockIdx.x % a.tiles_n;
+  }
+  const int64_t row0 = (int64_t)tr * kTile, col0 = (int64_t)tc * kTile;
+  Tile t;
+  t.zero();
+  t.mainloop(a.x1 + row0 * a.ld1, a.ld1, a.x2 + col0 * a.ld2, a.ld2, a.kp, smem);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const ElemProg<T, NET, ACT, NTK> prog(a.prog);
+  const int nsets = a.prog.nsets;
+
+  // stage the per-row / per-column layer tables of this tile in LDS (mainloop ended on a barrier)
+  T* srow = reinterpret_cast<T*>(smem);
+  T* scol = srow + nsets * 2 * kTile;
+  for (int idx = tid; idx < nsets * 2 * kTile; idx += 256) {
+    const int s2 = idx / kTile, r = idx % kTile;
+    srow[idx] = a.tab1[(int64_t)s2 * a.ldt1 + row0 + r];
+    scol[idx] = a.tab2[(int64_t)s2 * a.ldt2 + col0 + r];
+  }
+  __syncthreads();
+
+  typename Tile::acc_t th[Tile::MT][Tile::NT];
+#pragma unroll
+  for (int m = 0; m < Tile::MT; ++m)
+#pragma unroll
+    for (int n = 0; n < Tile::NT; ++n)
+#pragma unroll
+      for (int i = 0; i < M::ACC; ++i) {
+        T k = t.acc[m][n][i] * a.inv_d;
+        T h = T(0);
+        prog.pre(k, h);
+        t.acc[m][n][i] = k;
+        th[m][n][i] = h;
+      }
+
+  for (int s = 0; s < nsets; ++s) {
+    const T* sr = srow + s * 2 * kTile;
+    const T* sc = scol + s * 2 * kTile;
+    T cr[Tile::NT], cs[Tile::NT];
+#pragma unroll
+    for (int n = 0; n < Tile::NT; ++n) {
+      const int lc = wc * Tile::WN + n * M::TN + M::acc_col(lane);
+      cr[n] = sc[lc];
+      cs[n] = sc[kTile + lc];
+    }
+#pragma unroll
+    for (int m = 0; m < Tile::MT; ++m)
+#pragma unroll
+      for (int i = 0; i < M::ACC; ++i) {
+        const int lr = wr * Tile::WM + m * M::TM + M::acc_row(lane, i);
+        const T ri = sr[lr], si = sr[kTile + lr];
+#pragma unroll
+        for (int n = 0; n < Tile::NT; ++n) {
+          T k = t.acc[m][n][i], h = th[m][n][i];
+          prog.step(s, k, h, ri * cr[n], si * cs[n]);
+          t.acc[m][n][i] = k;
+          th[m][n][i] = h;
+        }
+      }
+  }
+
+  const bool do_mirror = a.symmetric && a.mirror && tr != tc;
+#pragma unroll
+  for (int m = 0; m < Tile::MT; ++m)
+#pragma unroll
+    for (int n = 0; n < Tile::NT; ++n)
+#pragma unroll
+      for (int i = 0; i < M::ACC; ++i) {
+        const int64_t gr = row0 + wr * Tile::WM + m * M::TM + M::acc_row(lane, i);
+        const int64_t gc = col0 + wc * Tile::WN + n * M::TN + M::acc_col(lane);
+        T k = t.acc[m][n][i], h = th[m][n][i];
+        prog.post(k, h);
+        if (a.exact_diag && gr + a.row_off == gc + a.col_off) k = a.dg[gr];
+        bool wr_ok;
+        if (a.store_mode == STORE_PAD_IDENTITY) {
+          const bool vr = gr < a.nv0 || (gr >= a.aug0 && gr < a.aug0 + a.nv1);
+          const bool vc = gc < a.nv0 || (gc >= a.aug0 && gc < a.aug0 + a.nv1);
+          if (!(vr && vc)) {
+            k = (gr == gc) ? T(1) : T(0);
+            h = k;
+          }
+          wr_ok = true;
+        } else {
+          wr_ok = gr < a.out_rows && gc < a.out_cols;
+        }
+        if (wr_ok) {
+          if (a.out_k) a.out_k[gr * a.ldo + gc] = k;
+          if (NTK && a.out_t) a.out_t[gr * a.ldo + gc] = h;
+        }
+        if (do_mirror && gc < a.out_rows && gr < a.out_cols) {
+          if (a.out_k) a.out_k[gc * a.ldo + gr] = k;
+          if (NTK && a.out_t) a.out_t[gc * a.ldo + gr] = h;
+        }
+      }
+}
+
+// ------------------------------------------------------------------ standalone recursion (HBM streaming)
+template <typename T>
+struct RecArgs {
+  const T* k0; int64_t ldk0; int64_t n1, n2;
+  const T* tab1; const T* tab2; int64_t ldt1, ldt2; const T* dg;
+  LayerProg prog; int exact_diag;
+  T* out_k; T* out_t; int64_t ldo; int rows_per_block;
+};
+
+// Block = 4 waves; blockIdx.x -> strip of 64*VEC columns, blockIdx.y -> group of rows.  A wave
+// streams one row segment at a time with 16-byte loads/stores; column tables live in LDS (read as
+// one b128 per table per layer), row tables are wave-uniform scalar loads.
+template <typename T, int NET, int ACT, bool NTK>
+__global__ void __launch_bounds__(256) recursion_kernel(RecArgs<T> a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int VEC = 16 / sizeof(T);
+  constexpr int COLS = 64 * VEC;
+  using vec_t = typename Mfma<T>::vec_t;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nsets = a.prog.nsets;
+  const int64_t col0 = (int64_t)blockIdx.x * COLS;
+  T* scol = reinterpret_cast<T*>(smem);   // [nsets][2][COLS]
+  for (int idx = tid; idx < nsets * 2 * COLS; idx += 256) {
+    const int s2 = idx / COLS, c = idx % COLS;
+    const int64_t gc = col0 + c;
+    scol[idx] = gc < a.n2 ? a.tab2[(int64_t)s2 * a.ldt2 + gc] : T(0);
+  }
+  __syncthreads();
+  const ElemProg<T, NET, ACT, NTK> prog(a.prog);
+  const int64_t gc = col0 + lane * VEC;
+  const int64_t rbeg = (int64_t)blockIdx.y * a.rows_per_block;
+  const int64_t rend = min(rbeg + a.rows_per_block, a.n1);
+  const bool full = gc + VEC <= a.n2;
+  for (int64_t row = rbeg + wave; row < rend; row += 4) {
+    vec_t kv;
+    if (full) {
+      kv = *reinterpret_cast<const vec_t*>(a.k0 + row * a.ldk0 + gc);
+    } else {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) kv[e] = gc + e < a.n2 ? a.k0[row * a.ldk0 + gc + e] : T(0);
+    }
+    vec_t hv;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      T k = kv[e], h = T(0);
+      prog.pre(k, h);
+      kv[e] = k;
+      hv[e] = h;
+    }
+    for (int s = 0; s < nsets; ++s) {
+      const T ri = a.tab1[(int64_t)(2 * s) * a.ldt1 + row];
+      const T si = a.tab1[(int64_t)(2 * s + 1) * a.ldt1 + row];
+      const vec_t cr = *reinterpret_cast<const vec_t*>(scol + (2 * s) * COLS + lane * VEC);
+      const vec_t cs = *reinterpret_cast<const vec_t*>(scol + (2 * s + 1) * COLS + lane * VEC);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        T k = kv[e], h = hv[e];
+        prog.step(s, k, h, ri * cr[e], si * cs[e]);
+        kv[e] = k;
+        hv[e] = h;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      T k = kv[e], h = hv[e];
+      prog.post(k, h);
+      if (a.exact_diag && row == gc + e) k = a.dg[row];
+      kv[e] = k;
+      hv[e] = h;
+    }
+    if (full) {
+      if (a.out_k) *reinterpret_cast<vec_t*>(a.out_k + row * a.ldo + gc) = kv;
+      if (NTK && a.out_t) *reinterpret_cast<vec_t*>(a.out_t + row * a.ldo + gc) = hv;
+    } else {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e)
+        if (gc + e < a.n2) {
+          if (a.out_k) a.out_k[row * a.ldo + gc + e] = kv[e];
+          if (NTK && a.out_t) a.out_t[row * a.ldo + gc + e] = hv[e];
+        }
+    }
+  }
+}
+
+// ------------------------------------------------------------------ host-side dispatch
+int make_prog(smn_ctx* ctx, const BuildSpec& s, LayerProg* p) {
+  if (s.net != SMN_NET_MLP && s.net != SMN_NET_DENSE_RESNET && s.net != NET_NONE)
+    return smn_fail(ctx, SMN_EINVAL, "unknown net %d", s.net);
+  if (s.act != SMN_ACT_RELU && s.act != SMN_ACT_ERF)
+    return smn_fail(ctx, SMN_EINVAL, "Unsupported act %d", s.act);   // nt_kernels.py:18 KeyError
+  if (s.num_hiddens < 0) return smn_fail(ctx, SMN_EINVAL, "num_hiddens < 0");
+  p->net = s.net;
+  p->act = s.act;
+  p->nsets = s.net == NET_NONE ? 0 : (s.net == SMN_NET_MLP ? s.num_hiddens : s.num_hiddens + 1);
+  if (p->nsets > kMaxSets) return smn_fail(ctx, SMN_ENOTSUP, "num_hiddens too large (max %d activation layers)", kMaxSets);
+  p->w2 = s.w_std * s.w_std;
+  p->b2 = s.b_std * s.b_std;
+  p->lw2 = s.last_w_std * s.last_w_std;
+  return SMN_OK;
+}
+
+template <typename T, int NET, int ACT, bool NTK>
+int launch_build_t(smn_ctx* ctx, const BuildArgs<T>& a, int64_t ntiles, size_t lds) {
+  auto kern = build_kernel<T, NET, ACT, NTK>;
+  SMN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3((unsigned)ntiles), dim3(256), lds, ctx->stream, a);
+  SMN_CHECK_LAUNCH(ctx);
+  return SMN_OK;
+}
+
+template <typename T, int NET, int ACT>
+int launch_build_n(smn_ctx* ctx, const BuildArgs<T>& a, int64_t ntiles, size_t lds, bool ntk) {
+  return ntk ? launch_build_t<T, NET, ACT, true>(ctx, a, ntiles, lds)
+             : launch_build_t<T, NET, ACT, false>(ctx, a, ntiles, lds);
+}
+
+template <typename T>
+int launch_build(smn_ctx* ctx, const BuildArgs<T>& a, int64_t ntiles, size_t lds, bool ntk) {
+  const int net = a.prog.net, act = a.prog.act;
+  if (net == NET_NONE) return launch_build_t<T, NET_NONE, ACT_RELU, false>(ctx, a, ntiles, lds);
+  if (net == NET_MLP && act == ACT_RELU) return launch_build_n<T, NET_MLP, ACT_RELU>(ctx, a, ntiles, lds, ntk);
+  if (net == NET_MLP && act == ACT_ERF) return launch_build_n<T, NET_MLP, ACT_ERF>(ctx, a, ntiles, lds, ntk);
+  if (net == NET_RESNET && act == ACT_RELU) return launch_build_n<T, NET_RESNET, ACT_RELU>(ctx, a, ntiles, lds, ntk);
+  return launch_build_n<T, NET_RESNET, ACT_ERF>(ctx, a, ntiles, lds, ntk);
+}
+
+template <typename T>
+int run_build_t(smn_ctx* ctx, const BuildCall& c) {
+  LayerProg prog;
+  SMN_TRY(make_prog(ctx, c.spec, &prog));
+  if (c.rows1 % kTile || c.rows2 % kTile || c.kp % Mfma<T>::BK)
+    return smn_fail(ctx, SMN_EINVAL, "run_build: operands not padded");
+  const bool ntk = (c.get_mask & SMN_GET_NTK) != 0;
+  if (ntk && prog.net == NET_NONE) return smn_fail(ctx, SMN_EINVAL, "NTK of a bare Gram");
+  // tables: [2*nsets + 1] rows of length rows1 (+ rows2 when not symmetric)
+  const int trows = 2 * prog.nsets + 1;
+  const int64_t tlen = c.symmetric ? c.rows1 : c.rows1 + c.rows2;
+  void* tabv = nullptr;
+  SMN_TRY(smn_workspace(ctx, 1, sizeof(T) * (size_t)trows * (size_t)tlen, &tabv));
+  T* tab1 = static_cast<T*>(tabv);
+  T* dg1 = tab1 + (int64_t)(2 * prog.nsets) * tlen;
+  hipLaunchKernelGGL(diag_tables_kernel<T>, dim3((unsigned)((c.rows1 + 255) / 256)), dim3(256), 0, ctx->stream,
+                     c.q1, c.rows1, prog, tab1, tlen, dg1);
+  SMN_CHECK_LAUNCH(ctx);
+  T* tab2 = tab1;
+  if (!c.symmetric) {
+    tab2 = tab1 + c.rows1;
+    hipLaunchKernelGGL(diag_tables_kernel<T>, dim3((unsigned)((c.rows2 + 255) / 256)), dim3(256), 0, ctx->stream,
+                       c.q2, c.rows2, prog, tab2, tlen, dg1 + c.rows1);
+    SMN_CHECK_LAUNCH(ctx);
+  }
+  BuildArgs<T> a;
+  a.x1 = static_cast<const T*>(c.x1p); a.x2 = static_cast<const T*>(c.x2p);
+  a.ld1 = c.ld1; a.ld2 = c.ld2; a.kp = c.kp;
+  const int64_t tm = c.rows1 / kTile, tn = c.rows2 / kTile;
+  a.tiles_n = (int)tn; a.symmetric = c.symmetric; a.mirror = c.mirror;
+  a.tab1 = tab1; a.tab2 = tab2; a.ldt1 = tlen; a.ldt2 = tlen; a.dg = dg1;
+  a.inv_d = (T)(1.0 / (double)c.d); a.prog = prog;
+  a.row_off = c.row_off; a.col_off = c.col_off; a.exact_diag = c.exact_diag;
+  a.store_mode = c.store_mode; a.out_rows = c.out_rows; a.out_cols = c.out_cols;
+  a.nv0 = c.nv0; a.aug0 = c.aug0; a.nv1 = c.nv1;
+  a.out_k = (c.get_mask & SMN_GET_NNGP) ? static_cast<T*>(c.out_k) : nullptr;
+  a.out_t = ntk ? static_cast<T*>(c.out_t) : nullptr;
+  a.ldo = c.ldo;
+  const int64_t ntiles = c.symmetric ? tm * (tm + 1) / 2 : tm * tn;
+  size_t lds = TileNT<T, kTile, kTile>::LDS_BYTES;
+  const size_t tab_lds = (size_t)prog.nsets * 2 * 2 * kTile * sizeof(T);
+  if (tab_lds > lds) lds = tab_lds;
+  return launch_build<T>(ctx, a, ntiles, lds, ntk);
+}
+
+template <typename T, int NET, int ACT, bool NTK>
+int launch_rec_t(smn_ctx* ctx, const RecArgs<T>& a, dim3 grid, size_t lds) {
+  hipLaunchKernelGGL((recursion_kernel<T, NET, ACT, NTK>), grid, dim3(256), lds, ctx->stream, a);
+  SMN_CHECK_LAUNCH(ctx);
+  return SMN_OK;
+}
+
+template <typename T>
+int launch_rec(smn_ctx* ctx, const RecArgs<T>& a, dim3 grid, size_t lds, bool ntk) {
+  const int net = a.prog.net, act = a.prog.act;
+#define REC_CASE(N, A)                                                        \
+  if (net == N && act == A)                                                   \
+    return ntk ? launch_rec_t<T, N, A, true>(ctx, a, grid, lds) : launch_rec_t<T, N, A, false>(ctx, a, grid, lds);
+  REC_CASE(NET_MLP, ACT_RELU)
+  REC_CASE(NET_MLP, ACT_ERF)
+  REC_CASE(NET_RESNET, ACT_RELU)
+  REC_CASE(NET_RESNET, ACT_ERF)
+#undef REC_CASE
+  return smn_fail(ctx, SMN_EINVAL, "recursion: bad net/act");
+}
+
+template <typename T>
+__global__ void cast_from_double_kernel(const double* __restrict__ s, T* __restrict__ d, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) d[i] = (T)s[i];
+}
+template <typename T>
+__global__ void cast_to_double_kernel(const T* __restrict__ s, double* __restrict__ d, int64_t n, int64_t npad) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < npad) d[i] = i < n ? (double)s[i] : 0.0;
+}
+
+template <typename T>
+int recursion_t(smn_ctx* ctx, const BuildSpec& spec, const void* k0, int64_t n1, int64_t n2, int64_t ldk0,
+                const void* q1, const void* q2, int symmetric, int get_mask, void* nngp, void* ntk, int64_t ldk) {
+  LayerProg prog;
+  SMN_TRY(make_prog(ctx, spec, &prog));
+  if (prog.net == NET_NONE) return smn_fail(ctx, SMN_EINVAL, "recursion needs a net");
+  const bool want_ntk = (get_mask & SMN_GET_NTK) != 0;
+  const int trows = 2 * prog.nsets + 1;
+  const int64_t tlen = n1 + n2;
+  void* tabv = nullptr;
+  SMN_TRY(smn_workspace(ctx, 1, sizeof(T) * (size_t)trows * tlen + sizeof(double) * (size_t)tlen, &tabv));
+  double* qd = static_cast<double*>(tabv);
+  T* tab1 = reinterpret_cast<T*>(qd + tlen);
+  T* dg1 = tab1 + (int64_t)(2 * prog.nsets) * tlen;
+  hipLaunchKernelGGL(cast_to_double_kernel<T>, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, ctx->stream,
+                     static_cast<const T*>(q1), qd, n1, n1);
+  hipLaunchKernelGGL(cast_to_double_kernel<T>, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, ctx->stream,
+                     static_cast<const T*>(q2), qd + n1, n2, n2);
+  hipLaunchKernelGGL(diag_tables_kernel<T>, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, ctx->stream,
+                     qd, n1, prog, tab1, tlen, dg1);
+  hipLaunchKernelGGL(diag_tables_kernel<T>, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, ctx->stream,
+                     qd + n1, n2, prog, tab1 + n1, tlen, dg1 + n1);
+  SMN_CHECK_LAUNCH(ctx);
+  RecArgs<T> a;
+  a.k0 = static_cast<const T*>(k0); a.ldk0 = ldk0; a.n1 = n1; a.n2 = n2;
+  a.tab1 = tab1; a.tab2 = tab1 + n1; a.ldt1 = tlen; a.ldt2 = tlen; a.dg = dg1;
+  a.prog = prog; a.exact_diag = symmetric;
+  a.out_k = (get_mask & SMN_GET_NNGP) ? static_cast<T*>(nngp) : nullptr;
+  a.out_t = want_ntk ? static_cast<T*>(ntk) : nullptr;
+  a.ldo = ldk; a.rows_per_block = 64;
+  constexpr int COLS = 64 * (16 / sizeof(T));
+  dim3 grid((unsigned)((n2 + COLS - 1) / COLS), (unsigned)((n1 + a.rows_per_block - 1) / a.rows_per_block));
+  const size_t lds = (size_t)prog.nsets * 2 * COLS * sizeof(T);
+  // 16-byte vector path needs aligned rows
+  if (ldk0 % (16 / sizeof(T)) || ldk % (16 / sizeof(T)) || (reinterpret_cast<uintptr_t>(k0) & 15) ||
+      (a.out_k && (reinterpret_cast<uintptr_t>(a.out_k) & 15)) || (a.out_t && (reinterpret_cast<uintptr_t>(a.out_t) & 15)))
+    return smn_fail(ctx, SMN_EINVAL, "smn_recursion: k0/out must be 16-byte aligned with ld %% %d == 0", (int)(16 / sizeof(T)));
+  return launch_rec<T>(ctx, a, grid, lds, want_ntk);
+}
+
+}  // namespace
+
+int pad_rows(smn_ctx* ctx, int dtype, const void* src, int64_t n, int64_t lds, int64_t d,
+             void* dst, int64_t rows_pad, int64_t kp, double* q) {
+  const unsigned blocks = (unsigned)((rows_pad + 3) / 4);
+  if (dtype == SMN_F64)
+    hipLaunchKernelGGL(pad_rows_kernel<double>, dim3(blocks), dim3(256), 0, ctx->stream, static_cast<const double*>(src),
+                       n, lds, d, static_cast<double*>(dst), rows_pad, kp, 1.0 / (double)d, q);
+  else
+    hipLaunchKernelGGL(pad_rows_kernel<float>, dim3(blocks), dim3(256), 0, ctx->stream, static_cast<const float*>(src),
+                       n, lds, d, static_cast<float*>(dst), rows_pad, kp, 1.0 / (double)d, q);
+  SMN_CHECK_LAUNCH(ctx);
+  return SMN_OK;
+}
+
+int run_build(smn_ctx* ctx, const BuildCall& c) {
+  return c.spec.dtype == SMN_F64 ? run_build_t<double>(ctx, c) : run_build_t<float>(ctx, c);
+}
+
+// ------------------------------------------------------------------ public entry points
+static int check_common(smn_ctx* ctx, int dtype, int64_t n1, int64_t n2, int64_t d) {
+  if (!ctx) return SMN_EINVAL;
+  if (dtype != SMN_F32 && dtype != SMN_F64) return smn_fail(ctx, SMN_EINVAL, "bad dtype %d", dtype);
+  if (n1 <= 0 || n2 <= 0 || d <= 0) return smn_fail(ctx, SMN_EINVAL, "empty operand (n1=%lld n2=%lld d=%lld)",
+                                                    (long long)n1, (long long)n2, (long long)d);
+  return SMN_OK;
+}
+
+// Shared by smn_kernel_mlp / smn_kernel_mlp_rows / smn_gram.
+static int build_public(smn_ctx* ctx, const BuildSpec& spec, const void* x1, int64_t n1, int64_t ldx1,
+                        const void* x2, int64_t n2, int64_t ldx2, int64_t d, int get_mask, int fill,
+                        int64_t row_begin, int64_t row_end, void* out_k, void* out_t, int64_t ldk,
+                        void* q1_out, void* q2_out) {
+  const int dtype = spec.dtype;
+  const size_t es = dtype_size(dtype);
+  const bool sym = (x2 == nullptr);
+  const int64_t kp = k_pad(dtype, d);
+  const int64_t r1 = round_up(n1, kTile), r2 = sym ? r1 : round_up(n2, kTile);
+  void* xs = nullptr;
+  const size_t xbytes = es * (size_t)kp * (size_t)(r1 + (sym ? 0 : r2)) + sizeof(double) * (size_t)(r1 + r2);
+  SMN_TRY(smn_workspace(ctx, 0, xbytes, &xs));
+  double* q1 = static_cast<double*>(xs);
+  double* q2 = q1 + r1;
+  char* x1p = reinterpret_cast<char*>(q2 + r2);
+  char* x2p = sym ? x1p : x1p + es * (size_t)kp * (size_t)r1;
+  SMN_TRY(pad_rows(ctx, dtype, x1, n1, ldx1, d, x1p, r1, kp, q1));
+  if (!sym) SMN_TRY(pad_rows(ctx, dtype, x2, n2, ldx2, d, x2p, r2, kp, q2));
+  BuildCall c{};
+  c.spec = spec;
+  c.kp = (int)kp; c.d = d; c.get_mask = get_mask;
+  c.out_k = out_k; c.out_t = out_t; c.ldo = ldk;
+  c.store_mode = STORE_BOUNDS;
+  if (row_end > row_begin) {            // row shard of the symmetric kernel: rows [rb,re) x all columns
+    const int64_t rb = row_begin, nr = row_end - row_begin;
+    const int64_t rr = round_up(nr, kTile);
+    // the padded copy has r1 rows; a shard's last tile may reach past it -> re-pad from the source
+    void* xr = nullptr;
+    SMN_TRY(smn_workspace(ctx, 3, es * (size_t)kp * (size_t)rr + sizeof(double) * (size_t)rr, &xr));
+    double* qr = static_cast<double*>(xr);
+    char* xrp = reinterpret_cast<char*>(qr + rr);
+    SMN_TRY(pad_rows(ctx, dtype, static_cast<const char*>(x1) + es * (size_t)rb * (size_t)ldx1, nr, ldx1, d, xrp, rr, kp, qr));
+    c.x1p = xrp; c.ld1 = kp; c.rows1 = rr; c.q1 = qr;
+    c.x2p = x1p; c.ld2 = kp; c.rows2 = r1; c.q2 = q1;
+    c.symmetric = 0; c.mirror = 0; c.row_off = rb; c.col_off = 0; c.exact_diag = 1;
+    c.out_rows = nr; c.out_cols = n1;
+    return run_build(ctx, c);
+  }
+  c.x1p = x1p; c.ld1 = kp; c.rows1 = r1; c.q1 = q1;
+  c.x2p = x2p; c.ld2 = kp; c.rows2 = r2; c.q2 = sym ? q1 : q2;
+  c.symmetric = sym ? 1 : 0; c.mirror = (sym && fill == SMN_FILL_FULL) ? 1 : 0;
+  c.exact_diag = sym ? 1 : 0;
+  c.out_rows = n1; c.out_cols = sym ? n1 : n2;
+  SMN_TRY(run_build(ctx, c));
+  if (q1_out || q2_out) {
+    const int64_t m1 = n1, m2 = sym ? n1 : n2;
+    if (dtype == SMN_F64) {
+      if (q1_out) SMN_HIP(ctx, hipMemcpyAsync(q1_out, q1, 8 * (size_t)m1, hipMemcpyDeviceToDevice, ctx->stream));
+      if (q2_out) SMN_HIP(ctx, hipMemcpyAsync(q2_out, sym ? q1 : q2, 8 * (size_t)m2, hipMemcpyDeviceToDevice, ctx->stream));
+    } else {
+      if (q1_out) hipLaunchKernelGGL(cast_from_double_kernel<float>, dim3((unsigned)((m1 + 255) / 256)), dim3(256), 0,
+                                     ctx->stream, q1, static_cast<float*>(q1_out), m1);
+      if (q2_out) hipLaunchKernelGGL(cast_from_double_kernel<float>, dim3((unsigned)((m2 + 255) / 256)), dim3(256), 0,
+                                     ctx->stream, sym ? q1 : q2, static_cast<float*>(q2_out), m2);
+      SMN_CHECK_LAUNCH(ctx);
+    }
+  }
+  return SMN_OK;
+}
+
+extern "C" int smn_kernel_mlp(smn_ctx* ctx, int dtype, int net, int act, int num_hiddens, double w_std,
+                              double b_std, double last_w_std, const void* x1_d, int64_t n1, int64_t ldx1,
+                              const void* x2_d, int64_t n2, int64_t ldx2, int64_t d, int get_mask, int fill,
+                              void* nngp_d, void* ntk_d, int64_t ldk) {
+  SMN_TRY(check_common(ctx, dtype, n1, x2_d ? n2 : 1, d));
+  if (!(get_mask & (SMN_GET_NNGP | SMN_GET_NTK))) return smn_fail(ctx, SMN_EINVAL, "empty get mask");
+  if (((get_mask & SMN_GET_NNGP) && !nngp_d) || ((get_mask & SMN_GET_NTK) && !ntk_d))
+    return smn_fail(ctx, SMN_EINVAL, "requested output pointer is NULL");
+  BuildSpec s{dtype, net, act, num_hiddens, w_std, b_std, last_w_std};
+  return build_public(ctx, s, x1_d, n1, ldx1, x2_d, n2, ldx2, d, get_mask, fill, 0, 0, nngp_d, ntk_d, ldk, nullptr, nullptr);
+}
+
+extern "C" int smn_kernel_mlp_rows(smn_ctx* ctx, int dtype, int net, int act, int num_hiddens, double w_std,
+                                   double b_std, double last_w_std, const void* x_d, int64_t n, int64_t ldx,
+                                   int64_t d, int64_t row_begin, int64_t row_end, int get_mask,
+                                   void* nngp_rows_d, void* ntk_rows_d, int64_t ldk) {
+  SMN_TRY(check_common(ctx, dtype, n, 1, d));
+  if (row_begin < 0 || row_end > n || row_end <= row_begin)
+    return smn_fail(ctx, SMN_EINVAL, "bad row range [%lld,%lld)", (long long)row_begin, (long long)row_end);
+  BuildSpec s{dtype, net, act, num_hiddens, w_std, b_std, last_w_std};
+  return build_public(ctx, s, x_d, n, ldx, nullptr, 0, 0, d, get_mask, SMN_FILL_FULL, row_begin, row_end,
+                      nngp_rows_d, ntk_rows_d, ldk, nullptr, nullptr);
+}
+
+extern "C" int smn_gram(smn_ctx* ctx, int dtype, const void* x1_d, int64_t n1, int64_t ldx1, const void* x2_d,
+                        int64_t n2, int64_t ldx2, int64_t d, void* k0_d, int64_t ldk, void* q1_d, void* q2_d) {
+  SMN_TRY(check_common(ctx, dtype, n1, x2_d ? n2 : 1, d));
+  BuildSpec s{dtype, NET_NONE, SMN_ACT_RELU, 0, 1.0, 0.0, 1.0};
+  return build_public(ctx, s, x1_d, n1, ldx1, x2_d, n2, ldx2, d, SMN_GET_NNGP, SMN_FILL_FULL, 0, 0, k0_d, nullptr,
+                      ldk, q1_d, q2_d);
+}
+
+extern "C" int smn_recursion(smn_ctx* ctx, int dtype, int net, int act, int num_hiddens, double w_std, double b_std,
+                             double last_w_std, const void* k0_d, int64_t n1, int64_t n2, int64_t ldk0,
+                             const void* q1_d, const void* q2_d, int symmetric, int get_mask, void* nngp_d,
+                             void* ntk_d, int64_t ldk) {
+  SMN_TRY(check_common(ctx, dtype, n1, n2, 1));
+  BuildSpec s{dtype, net, act, num_hiddens, w_std, b_std, last_w_std};
+  if (dtype == SMN_F64)
+    return recursion_t<double>(ctx, s, k0_d, n1, n2, ldk0, q1_d, q2_d, symmetric, get_mask, nngp_d, ntk_d, ldk);
+  return recursion_t<float>(ctx, s, k0_d, n1, n2, ldk0, q1_d, q2_d, symmetric, get_mask, nngp_d, ntk_d, ldk);
+}

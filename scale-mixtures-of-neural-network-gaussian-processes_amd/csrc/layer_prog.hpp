@@ -1,0 +1,67 @@
+// layer_prog.hpp — the layer stack of experiments/nt_kernels.py as a per-element program.
+//
+//   MLP (nt_kernels.py:21-31):      L x [Dense(w,b); act];  Dense(last_w, b=0)
+//   dense ResNet (nt_kernels.py:83-103):  Dense(w,b);  L x {K <- [act; Dense(w,b)](K) + K};  act;  Dense(last_w,0)
+//
+// Dense:  K <- w^2 K + b^2,  Theta <- K_new + w^2 Theta      (NTK parameterisation)
+// act:    (K, Kdot) <- map(K; r_i r_j, s_i s_j),  Theta <- Theta * Kdot      (A.2)
+//
+// One "set" = one activation with its per-row tables (r, s); MLP has L sets, ResNet L + 1.
+#pragma once
+#include "nngp_math.hpp"
+
+enum { NET_MLP = 0, NET_RESNET = 1, NET_NONE = 2 };
+enum { ACT_RELU = 0, ACT_ERF = 1 };
+constexpr int kMaxSets = 16;
+
+struct LayerProg {  // plain-old-data kernel argument
+  int net, act, nsets;
+  double w2, b2, lw2;
+};
+
+template <typename T, int NET, int ACT, bool NTK>
+struct ElemProg {
+  T w2, b2, lw2;
+  int nsets;
+  __device__ __forceinline__ explicit ElemProg(const LayerProg& p)
+      : w2((T)p.w2), b2((T)p.b2), lw2((T)p.lw2), nsets(p.nsets) {}
+
+  static __device__ __forceinline__ nngp::ActOut<T> act(T k, T rr, T ss) {
+    if (ACT == ACT_RELU) return nngp::relu_map<T, NTK>(k, rr, ss);
+    return nngp::erf_map<T, NTK>(k, rr, ss);
+  }
+  __device__ __forceinline__ void pre(T& k, T& th) const {
+    if (NET == NET_RESNET) {
+      k = fma(w2, k, b2);
+      if (NTK) th = k;
+    } else if (NTK) {
+      th = T(0);
+    }
+  }
+  __device__ __forceinline__ void step(int set, T& k, T& th, T rr, T ss) const {
+    if (NET == NET_MLP) {
+      const T kt = fma(w2, k, b2);
+      T tht = T(0);
+      if (NTK) tht = fma(w2, th, kt);
+      const nngp::ActOut<T> o = act(kt, rr, ss);
+      k = o.k;
+      if (NTK) th = tht * o.kdot;
+    } else if (NET == NET_RESNET) {
+      const nngp::ActOut<T> o = act(k, rr, ss);
+      if (set == nsets - 1) {
+        k = o.k;
+        if (NTK) th *= o.kdot;
+      } else {
+        const T ka = fma(w2, o.k, b2);
+        if (NTK) th += fma(w2, th * o.kdot, ka);
+        k += ka;
+      }
+    }
+  }
+  __device__ __forceinline__ void post(T& k, T& th) const {
+    if (NET != NET_NONE) {
+      k *= lw2;
+      if (NTK) th = fma(lw2, th, k);
+    }
+  }
+};

@@ -1,0 +1,83 @@
+// nngp_math.hpp — the per-element nonlinear maps of the NNGP / NTK layer recursion.
+//
+// Math (neural_tangents stax.Relu / stax.Erf kernel transforms composed
+// by experiments/nt_kernels.py:21-31):
+//   ReLU:  c = K / sqrt(q_i q_j);  K' = sqrt(q_i q_j)/(2 pi) * J(c),  J(c) = sqrt(1-c^2) + (pi - acos c) c
+//          Kdot = (pi - acos c) / (2 pi)
+//   Erf:   c = 2K / sqrt((1+2q_i)(1+2q_j));  K' = (2/pi) asin c;  Kdot = 4 / (pi sqrt((1+2q_i)(1+2q_j) - 4K^2))
+// The per-row factors r_i, s_i are precomputed per layer (diag_tables kernel), so per element:
+//   ReLU:  c = clamp(K r_i r_j),  K' = s_i s_j J(c)          r = 1/sqrt(q),  s = sqrt(q / (2 pi))
+//   Erf:   c = clamp(2 K r_i r_j), K' = (2/pi) asin(c)        r = 1/sqrt(1+2q)
+// J is written with asin so that one odd/even split serves both signs without cancellation:
+//   J(c) = (pi/2) c + sqrt(1-c^2) + |c| asin|c|,   pi - acos c = pi/2 + asin c.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace nngp {
+
+constexpr double kPi = 3.14159265358979323846;
+
+template <typename T>
+struct ActOut {
+  T k;     // K'
+  T kdot;  // Kdot (only meaningful when requested)
+};
+
+// asin(|c|) for |c| <= 1, f32: fdlibm-style split, branch-free, ~1.2 ulp.
+//   |c| <= 0.5 : asin(a) = a + a t P(t), t = a^2
+//   |c| >  0.5 : asin(a) = pi/2 - 2 asin(s), s = sqrt((1-a)/2), same polynomial with t = s^2
+// P fitted on [0, 0.25] (minimax-refined least squares), max rel. err 6.8e-8 in f32 arithmetic.
+__device__ __forceinline__ float asin_abs(float a, float c2) {
+  const float z = fmaf(-0.5f, a, 0.5f);
+  const float s = __builtin_amdgcn_sqrtf(z);
+  const bool big = a > 0.5f;
+  const float t = big ? z : c2;
+  const float p = big ? s : a;
+  float r = 0.041802484542131424f;
+  r = fmaf(r, t, 0.02439034730195999f);
+  r = fmaf(r, t, 0.04542740806937218f);
+  r = fmaf(r, t, 0.07495657354593277f);
+  r = fmaf(r, t, 0.1666674166917801f);
+  r = fmaf(p * t, r, p);
+  return big ? fmaf(-2.0f, r, 1.57079632679489662f) : r;
+}
+__device__ __forceinline__ double asin_abs(double a, double /*c2*/) { return asin(a); }
+
+__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ double fast_sqrt(double x) { return sqrt(x); }
+__device__ __forceinline__ float fast_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ double fast_rsqrt(double x) { return 1.0 / sqrt(x); }
+
+template <typename T>
+__device__ __forceinline__ T clamp1(T c) {
+  return fmin(fmax(c, T(-1)), T(1));
+}
+
+// ReLU map.  kt = pre-activation covariance, rr = r_i r_j, ss = s_i s_j.
+template <typename T, bool WANT_DOT>
+__device__ __forceinline__ ActOut<T> relu_map(T kt, T rr, T ss) {
+  const T c = clamp1(kt * rr);
+  const T a = fabs(c);
+  const T c2 = c * c;
+  const T as = asin_abs(a, c2);
+  const T sq = fast_sqrt(fma(-c, c, T(1)));
+  const T j = fma(T(kPi / 2), c, fma(a, as, sq));
+  ActOut<T> o;
+  o.k = ss * j;
+  if (WANT_DOT) o.kdot = fma(copysign(as, c), T(1.0 / (2.0 * kPi)), T(0.25));
+  return o;
+}
+
+// Erf map.  rr = r_i r_j with r = 1/sqrt(1+2q).
+template <typename T, bool WANT_DOT>
+__device__ __forceinline__ ActOut<T> erf_map(T kt, T rr, T /*ss*/) {
+  const T c = clamp1(T(2) * kt * rr);
+  const T a = fabs(c);
+  const T as = asin_abs(a, c * c);
+  ActOut<T> o;
+  o.k = T(2.0 / kPi) * copysign(as, c);
+  if (WANT_DOT) o.kdot = T(4.0 / kPi) * rr * fast_rsqrt(fma(-c, c, T(1)));
+  return o;
+}
+
+}  // namespace nngp

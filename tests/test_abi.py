@@ -1,0 +1,80 @@
+"""CPU-side checks of the boundary: the C-ABI library loads without a GPU and exports every symbol
+include/smnngp.h declares; the ctypes table covers exactly those symbols; no compute calls here."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "smnngp.h")
+
+
+def declared_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\bint\s+(smn_[a-z0-9_]+)\s*\(", src)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as g
+    g.build()
+    from smnngp import _lib
+    return _lib
+
+
+def test_library_exports_every_declared_symbol(lib):
+    names = declared_symbols()
+    assert len(names) >= 25
+    raw = ctypes.CDLL(lib.LIB_PATH)
+    for n in names:
+        assert hasattr(raw, n), "libsmnngp.so does not export %s" % n
+    assert sorted(lib.PROTOTYPES) == names, set(lib.PROTOTYPES) ^ set(names)
+
+
+def test_prototype_arity_matches_header(lib):
+    src = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    for name, args in lib.PROTOTYPES.items():
+        m = re.search(r"\bint\s+%s\s*\((.*?)\)\s*;" % name, src, flags=re.S)
+        assert m, name
+        body = m.group(1).strip()
+        n = 0 if body in ("", "void") else len(body.split(","))
+        assert n == len(args), (name, n, len(args))
+
+
+def test_version_and_no_device_fails_loudly(lib):
+    assert lib._lib.smn_version() >= 100
+    if os.path.exists("/dev/kfd"):
+        pytest.skip("GPU present")
+    with pytest.raises(lib.SmnError):
+        lib.Context()
+
+
+def test_product_does_not_import_the_oracle():
+    pkg = os.path.join(ROOT, "scale-mixtures-of-neural-network-gaussian-processes_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp")):
+                text = open(os.path.join(dp, f)).read()
+                assert "oracle" not in text.lower() or f == "build.py", os.path.join(dp, f)
+
+
+def test_lazy_device_array_algebra_is_symbolic(lib):
+    j = lib.ScaledIdentity(4, 0.5)
+    assert np.allclose(np.asarray(2.0 * j), np.eye(4))
+    from smnngp.spax.utils import jitter
+    assert isinstance(jitter(3, 1e-6), lib.ScaledIdentity) and jitter(3).eps == 1e-6
+
+
+def test_bijectors_and_trainvars():
+    from smnngp.spax.base import ConstraintTrainVar
+    from smnngp.spax.bijectors import positive
+    for v in (1e-8, 1e-6, 0.3, 1.0, 19.0, 25.0):
+        assert abs(ConstraintTrainVar(v, positive()).safe_value - v) <= 1e-9 * max(v, 1.0) + 1e-16
+    assert ConstraintTrainVar(25.0, positive()).value == 25.0        # bijectors.py:53 guard
+    assert abs(ConstraintTrainVar(0.7, positive(base="exp")).safe_value - 0.7) < 1e-12
+    with pytest.raises(NotImplementedError):
+        from smnngp.spax.bijectors import triangular
+        triangular()

@@ -1,0 +1,287 @@
+"""GPU parity tests: the HIP path (through the C-ABI / the spax facade) against the CPU oracle on the
+same seeded inputs.  Tolerances are the north-star's: 1e-5 relative in fp64 (asserted tighter where the
+arithmetic allows), 1e-2 relative in fp32 (asserted at 2e-3 or better)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import scipy.linalg as sla
+
+pytestmark = pytest.mark.gpu
+
+from oracle import nngp_oracle as O  # noqa: E402  (test infrastructure only)
+
+RTOL = {np.float32: 2e-3, np.float64: 1e-8}
+
+
+@pytest.fixture(scope="module")
+def L():
+    from smnngp import _lib
+    return _lib
+
+
+@pytest.fixture(scope="module")
+def ctx(L):
+    return L.default_context()
+
+
+def relerr(a, b):
+    a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+    return np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300)
+
+
+# ----------------------------------------------------------------------------- kernel build
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("act", ["relu", "erf"])
+@pytest.mark.parametrize("net", ["mlp", "resnet"])
+@pytest.mark.parametrize("n,d,layers", [(33, 6, 2), (200, 50, 4), (129, 3072, 1)])
+def test_symmetric_kernel_nngp_ntk(dtype, act, net, n, d, layers):
+    from smnngp import nt_kernels
+    rng = np.random.default_rng(10 + n)
+    x = rng.standard_normal((n, d)).astype(dtype)
+    w, b, lw = 1.4, 0.3, 0.8
+    fac = nt_kernels.get_mlp_kernel if net == "mlp" else nt_kernels.get_dense_resnet_kernel
+    ofn = O.mlp_kernel if net == "mlp" else O.dense_resnet_kernel
+    kfn = fac(layers, act=act, w_std=w, b_std=b, last_w_std=lw)
+    got = kfn(x, None, get=("nngp", "ntk"))
+    rk, rt = ofn(x.astype(np.float64), None, layers, act, w, b, lw, ("nngp", "ntk"))
+    k, t = np.asarray(got.nngp), np.asarray(got.ntk)
+    assert k.dtype == dtype and k.shape == (n, n)
+    assert relerr(k, rk) < RTOL[dtype]
+    assert relerr(t, rt) < RTOL[dtype] * 5
+    assert np.array_equal(k, k.T)                      # mirrored store is exact
+    # single get / lower fill
+    k2 = np.asarray(kfn(x, x, get="nngp"))
+    assert np.array_equal(k2, k)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("act", ["relu", "erf"])
+def test_cross_kernel_and_zero_bias_defaults(dtype, act):
+    from smnngp import nt_kernels
+    rng = np.random.default_rng(3)
+    x1 = rng.standard_normal((300, 17)).astype(dtype)
+    x2 = rng.standard_normal((130, 17)).astype(dtype)
+    kfn = nt_kernels.get_mlp_kernel(3, act=act)          # defaults w=1, b=0, lw=1 (nt_kernels.py:21)
+    k = np.asarray(kfn(x1, x2, get="nngp"))
+    ref = O.mlp_kernel(x1.astype(np.float64), x2.astype(np.float64), 3, act, 1.0, 0.0, 1.0)
+    assert k.shape == (300, 130)
+    assert relerr(k, ref) < RTOL[dtype]
+    # reference default b_std = 1e-8 (regression/train.py:43)
+    kfn = nt_kernels.get_mlp_kernel(2, act=act, w_std=1.0, b_std=1e-8, last_w_std=1.0)
+    k = np.asarray(kfn(x2, None, get="nngp"))
+    assert relerr(k, O.mlp_kernel(x2.astype(np.float64), None, 2, act, 1.0, 1e-8, 1.0)) < RTOL[dtype]
+
+
+def test_bad_arguments_raise(L, ctx):
+    from smnngp import nt_kernels
+    with pytest.raises(KeyError):
+        nt_kernels.get_mlp_kernel(2, act="tanh")
+    kfn = nt_kernels.get_mlp_kernel(2)
+    with pytest.raises(ValueError):
+        kfn(np.zeros((4, 3)), np.zeros((4, 5)))
+    with pytest.raises(ValueError):
+        kfn(np.zeros((4, 3)), None, get="bogus")
+    with pytest.raises(L.SmnError):
+        nt_kernels.get_mlp_kernel(40)(np.ones((4, 3)))      # more activation layers than supported
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_gram_then_recursion_equals_fused(L, ctx, dtype):
+    rng = np.random.default_rng(5)
+    n1, n2, d = 260, 132, 40
+    x1 = ctx.to_device(rng.standard_normal((n1, d)).astype(dtype))
+    x2 = ctx.to_device(rng.standard_normal((n2, d)).astype(dtype))
+    code = L.dtype_code(dtype)
+    k0 = ctx.empty((n1, n2), dtype); q1 = ctx.empty((n1,), dtype); q2 = ctx.empty((n2,), dtype)
+    ctx.call("smn_gram", code, x1.ptr, n1, d, x2.ptr, n2, d, d, k0.ptr, n2, q1.ptr, q2.ptr)
+    rk0, rq1, rq2 = O.input_gram(x1.numpy().astype(np.float64), x2.numpy().astype(np.float64))
+    assert relerr(k0.numpy(), rk0) < RTOL[dtype] and relerr(q1.numpy(), rq1) < RTOL[dtype]
+    assert relerr(q2.numpy(), rq2) < RTOL[dtype]
+    for act in ("relu", "erf"):
+        k = ctx.empty((n1, n2), dtype); t = ctx.empty((n1, n2), dtype)
+        ctx.call("smn_recursion", code, L.NET_MLP, L.ACT[act], 3, 1.3, 0.2, 0.9, k0.ptr, n1, n2, n2, q1.ptr, q2.ptr,
+                 0, L.GET_NNGP | L.GET_NTK, k.ptr, t.ptr, n2)
+        rk, rt = O.mlp_kernel(x1.numpy().astype(np.float64), x2.numpy().astype(np.float64), 3, act, 1.3, 0.2, 0.9,
+                              ("nngp", "ntk"))
+        assert relerr(k.numpy(), rk) < RTOL[dtype]
+        assert relerr(t.numpy(), rt) < RTOL[dtype] * 5
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_row_shard_equals_rows_of_full_kernel(L, ctx, dtype):
+    rng = np.random.default_rng(6)
+    n, d = 301, 24
+    xh = rng.standard_normal((n, d)).astype(dtype)
+    x = ctx.to_device(xh)
+    ref = O.mlp_kernel(xh.astype(np.float64), None, 2, "relu", 1.2, 0.1, 1.0)
+    for rb, re in ((0, 76), (76, 200), (200, 301)):
+        out = ctx.empty((re - rb, n), dtype)
+        ctx.call("smn_kernel_mlp_rows", L.dtype_code(dtype), L.NET_MLP, L.ACT["relu"], 2, 1.2, 0.1, 1.0, x.ptr, n, d, d,
+                 rb, re, L.GET_NNGP, out.ptr, None, n)
+        assert relerr(out.numpy(), ref[rb:re]) < RTOL[dtype]
+
+
+# ----------------------------------------------------------------------------- factorisation
+def _spd(rng, n, dtype, cond=1e3):
+    a = rng.standard_normal((n, n))
+    q, _ = np.linalg.qr(a)
+    ev = np.geomspace(1.0, cond, n)
+    return ((q * ev) @ q.T).astype(dtype)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("n,m", [(128, 0), (300, 0), (256, 128), (391, 37), (1024, 0)])
+def test_cholesky_and_schur(L, ctx, dtype, n, m):
+    rng = np.random.default_rng(n + m)
+    a = _spd(rng, n + m, np.float64)
+    ad = ctx.to_device(a.astype(dtype))
+    info, logdet = C.c_int(), C.c_double()
+    ctx.call("smn_cholesky", L.dtype_code(dtype), ad.ptr, n + m, n, n + m, 0, 0.0, 0.0, C.byref(info), C.byref(logdet))
+    got = ad.numpy().astype(np.float64)
+    l = np.linalg.cholesky(a[:n, :n])
+    tol = 1e-9 if dtype == np.float64 else 5e-3
+    assert info.value == 0
+    assert abs(logdet.value - 2 * np.log(np.diag(l)).sum()) < tol * max(1.0, abs(logdet.value))
+    assert relerr(np.tril(got[:n, :n]), l) < tol
+    if m:
+        w = sla.solve_triangular(l, a[:n, n:], lower=True).T        # B L^-T
+        assert relerr(got[n:, :n], w) < tol
+        s = a[n:, n:] - w @ w.T
+        assert relerr(np.tril(got[n:, n:]), np.tril(s)) < tol
+
+
+def test_cholesky_shift_and_not_pd(L, ctx):
+    rng = np.random.default_rng(11)
+    n = 200
+    a = _spd(rng, n, np.float64)
+    ad = ctx.to_device(a)
+    info, logdet = C.c_int(), C.c_double()
+    ctx.call("smn_cholesky", L.F64, ad.ptr, n, n, n, n, 0.5, 0.25, C.byref(info), C.byref(logdet))
+    ref = a + (0.5 + 0.25 * np.trace(a) / n) * np.eye(n)
+    assert abs(logdet.value - np.linalg.slogdet(ref)[1]) < 1e-9 * abs(logdet.value)
+    bad = a.copy(); bad[150, 150] = -1.0
+    bd = ctx.to_device(bad)
+    ctx.call("smn_cholesky", L.F64, bd.ptr, n, n, n, 0, 0.0, 0.0, C.byref(info), C.byref(logdet))
+    assert info.value == 151 and np.isnan(logdet.value)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_trsm_lower(L, ctx, dtype):
+    rng = np.random.default_rng(12)
+    n, r = 333, 45
+    l = np.linalg.cholesky(_spd(rng, n, np.float64, cond=100.0))
+    b = rng.standard_normal((n, r))
+    ld = ctx.to_device(l.astype(dtype)); bd = ctx.to_device(b.astype(dtype))
+    ctx.call("smn_trsm", L.dtype_code(dtype), ld.ptr, n, n, bd.ptr, r, r, 0)
+    ref = sla.solve_triangular(l, b, lower=True)
+    assert relerr(bd.numpy(), ref) < (1e-9 if dtype == np.float64 else 2e-3)
+
+
+# ----------------------------------------------------------------------------- heads
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_lml_gaussian_and_student_t(L, ctx, dtype):
+    rng = np.random.default_rng(13)
+    n = 270
+    x = rng.standard_normal((n, 5)); y = rng.standard_normal(n)
+    k = O.mlp_kernel(x, None, 2, "relu", 1.0, 0.5, 1.0)
+    eps = 1e-2
+    kd = ctx.to_device(k.astype(dtype)); yd = ctx.to_device(y.astype(dtype))
+    lp, quad, logdet, info = C.c_double(), C.c_double(), C.c_double(), C.c_int()
+    code = L.dtype_code(dtype)
+    tol = 1e-8 if dtype == np.float64 else 2e-3
+    ctx.call("smn_lml", code, kd.ptr, n, n, yd.ptr, eps, 0.0, 1.0, C.byref(lp), C.byref(quad), C.byref(logdet), C.byref(info))
+    ref = O.mvn_logpdf(y, k + eps * np.eye(n))
+    assert info.value == 0 and abs(lp.value - ref) < tol * abs(ref)
+    kd = ctx.to_device(k.astype(dtype))
+    ctx.call("smn_lml", code, kd.ptr, n, n, yd.ptr, eps, 4.0, 1.5, C.byref(lp), None, None, C.byref(info))
+    ref = O.mvt_logpdf(y, 1.5 * (k + eps * np.eye(n)), 4.0)
+    assert abs(lp.value - ref) < tol * abs(ref)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("n,t,c", [(245, 30, 1), (130, 140, 3)])
+def test_predict_joint_and_fused(L, ctx, dtype, n, t, c):
+    from smnngp import nt_kernels, predict
+    rng = np.random.default_rng(14 + n)
+    d = 6
+    x = rng.standard_normal((n, d)).astype(dtype); xt = rng.standard_normal((t, d)).astype(dtype)
+    y = rng.standard_normal((n, c)).astype(dtype)
+    kw = dict(num_hiddens=2, act="relu", w_std=1.1, b_std=0.4, last_w_std=1.0)
+    x64, xt64 = x.astype(np.float64), xt.astype(np.float64)
+    kdd = O.mlp_kernel(x64, None, **kw); ktd = O.mlp_kernel(xt64, x64, **kw); ktt = O.mlp_kernel(xt64, None, **kw)
+    eps = 1e-3 if dtype == np.float64 else 1e-2
+    rmean, rcov = O.predict(kdd, ktd, ktt, y.astype(np.float64), diag_reg=eps)
+    kfn = nt_kernels.get_mlp_kernel(2, act="relu", w_std=1.1, b_std=0.4, last_w_std=1.0)
+    pf = predict.gradient_descent_mse_ensemble(kfn, x, y, diag_reg=eps)
+    res = pf(x_test=xt, get="nngp", compute_cov=True)
+    mean, cov = np.asarray(res[0]), np.asarray(res[1])
+    tol = 1e-7 if dtype == np.float64 else 1e-2
+    assert mean.shape == (t, c) and cov.shape == (t, t)
+    assert relerr(mean, rmean) < tol and relerr(cov, rcov) < tol
+    kt = kdd + eps * np.trace(kdd) / n * np.eye(n)
+    rquad = [float(y[:, k].astype(np.float64) @ np.linalg.solve(kt, y[:, k].astype(np.float64))) for k in range(c)]
+    assert np.allclose(res.quad, rquad, rtol=tol)
+    # generic kernel_fn path (joint kernel handed to smn_predict)
+    pf2 = predict.gradient_descent_mse_ensemble(lambda a, b, g: kfn(a, b, g), x, y, diag_reg=eps)
+    m2, c2 = pf2(x_test=xt)
+    assert relerr(np.asarray(m2), rmean) < tol and relerr(np.asarray(c2), rcov) < tol
+
+
+# ----------------------------------------------------------------------------- spax facade == the reference's call sequence
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("method", ["gp", "tp"])
+@pytest.mark.parametrize("network", ["mlp", "resnet"])
+def test_spr_loss_and_test_nll(dtype, method, network):
+    """Mirrors experiments/regression/train.py:126-142,61-74 on the syn-t generator (data.py:229-236)."""
+    from smnngp import nt_kernels
+    from smnngp.spax.kernels import NNGPKernel
+    from smnngp.spax.likelihoods import GaussianLikelihood, StudentTLikelihood
+    from smnngp.spax.models import SPR
+    num = 300
+    rs = np.random.RandomState(761)
+    xx = np.linspace(-num / 2, num / 2, num)[:, None]
+    cov = np.exp(-0.5 * (xx - xx.T) ** 2)
+    yy = rs.multivariate_normal(mean=np.zeros(num), cov=cov, size=1).flatten() + rs.standard_t(df=1, size=num) * 0.8
+    idx = np.random.RandomState(10).permutation(num)
+    xx, yy = xx[idx], yy[idx]
+    ntr = 240
+    xm, xs = xx[:ntr].mean(0), xx[:ntr].std(0); ym, ys = yy[:ntr].mean(), yy[:ntr].std()
+    xtr, xte = (xx[:ntr] - xm) / xs, (xx[ntr:] - xm) / xs
+    ytr, yte = (yy[:ntr] - ym) / ys, (yy[ntr:] - ym) / ys
+    nh, act, ws, bs, ls, eps, al, be = 2, "relu", 1.0, 0.3, 1.0, 1e-2, 2.0, 2.0
+    base = nt_kernels.get_mlp_kernel if network == "mlp" else nt_kernels.get_dense_resnet_kernel
+
+    def get_kernel_fn(w_std, b_std, last_w_std):
+        return base(nh, 1, act=act, w_std=w_std, b_std=b_std, last_w_std=last_w_std)
+
+    kernel = NNGPKernel(get_kernel_fn, ws, bs, ls)
+    lik = GaussianLikelihood() if method == "gp" else StudentTLikelihood(al, be)
+    model = SPR(kernel, lik, xtr.astype(dtype), ytr.astype(dtype), ym, ys, eps=eps)
+    okw = dict(kernel=network, num_hiddens=nh, act=act, w_std=ws, b_std=bs, last_w_std=ls, eps=eps, method=method,
+               alpha=al, beta=be)
+    rl = O.spr_loss(xtr, ytr, **okw)
+    rn = O.spr_test_nll(xtr, ytr, xte, yte, ym, ys, **okw)
+    tol = 1e-7 if dtype == np.float64 else 1e-2
+    assert abs(model.loss() - rl) < tol * max(1.0, abs(rl))
+    assert abs(model.test_nll(xte.astype(dtype), yte.astype(dtype)) - rn) < tol * max(1.0, abs(rn))
+    # trainables round-trip through the softplus constraint (spax/base.py:15-25)
+    assert abs(kernel.w_std.safe_value - ws) < 1e-12 and abs(model.eps.safe_value - eps) < 1e-12
+    # the un-fused path (generic kernel_fn -> K + jitter -> prior_logpdf) gives the same number
+    kernel2 = NNGPKernel(lambda w, b, l: (lambda a, c, get: get_kernel_fn(w, b, l)(a, c, get)), ws, bs, ls)
+    model2 = SPR(kernel2, lik, xtr.astype(dtype), ytr.astype(dtype), ym, ys, eps=eps)
+    assert abs(model2.loss() - rl) < tol * max(1.0, abs(rl))
+    assert abs(model2.test_nll(xte.astype(dtype), yte.astype(dtype)) - rn) < tol * max(1.0, abs(rn))
+
+
+def test_not_pd_gives_nan_like_the_reference():
+    """JAX's Cholesky returns NaN on a non-PD matrix and the driver notices later (train.py:211)."""
+    from smnngp import nt_kernels
+    from smnngp.spax.kernels import NNGPKernel
+    from smnngp.spax.likelihoods import GaussianLikelihood
+    from smnngp.spax.models import SPR
+    x = np.ones((40, 3))                                   # rank-1 kernel, eps tiny -> not PD in fp32
+    y = np.linspace(-1, 1, 40)
+    k = NNGPKernel(lambda w, b, l: nt_kernels.get_mlp_kernel(1, act="relu", w_std=w, b_std=b, last_w_std=l), 1., 1e-8, 1.)
+    m = SPR(k, GaussianLikelihood(), x.astype(np.float32), y.astype(np.float32), 0.0, 1.0, eps=1e-12)
+    assert np.isnan(m.loss())
