@@ -1,0 +1,267 @@
+#!/usr/bin/env python3
+"""bench.py — the hot path of BASELINE.json on MI355X: NNGP kernel build + jittered Cholesky (+ LML heads).
+
+One "step" = one SPR.loss evaluation (spax/models.py:93-98) on synthetic inputs already resident in HBM:
+fused Gram + 4-layer ReLU recursion -> K + eps I -> blocked Cholesky with y carried -> log-marginal
+likelihood.  Workload at N=1: BASELINE.json configs[3] shape on one GPU (N=16384, d=3072, L=4, fp32).
+With --gpus P > 1 (launched by torch.distributed.run, one rank per GPU): the kernel build is row-sharded
+over the ranks, assembled with ONE RCCL all-gather, and every rank factors the assembled kernel
+(strong scaling: total work fixed).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_F64_MFMA_TFLOPS = 78.6    # datasheet (not in the local guide)
+PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s achievable)
+TILE = 128
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=5)
+    p.add_argument("--warmup", type=int, default=2)
+    p.add_argument("--n", type=int, default=16384)
+    p.add_argument("--d", type=int, default=3072)
+    p.add_argument("--layers", type=int, default=4)
+    p.add_argument("--act", default="relu")
+    p.add_argument("--dtype", default="f32", choices=["f32", "f64"])
+    p.add_argument("--eps", type=float, default=None)
+    p.add_argument("--cpu-sample-n", type=int, default=4096)
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-recursion-probe", action="store_true")
+    return p.parse_args()
+
+
+def cholesky_launch_model(n_total, n_factor):
+    """Flops EXECUTED by the trailing / strip update launches of csrc/cholesky.hip (full 128x128 tiles)."""
+    trail = strip = 0.0
+    n_trail = n_strip = 0
+    W = 2 * TILE
+    j0 = 0
+    while j0 < n_factor:
+        w = min(W, n_factor - j0)
+        js = j0
+        while js < j0 + w:
+            if js > j0:
+                strip += ((n_total - js) // TILE) * TILE * TILE * 2.0 * (js - j0)
+                n_strip += 1
+            js += TILE
+        j1 = j0 + w
+        if j1 < n_total:
+            t = (n_total - j1) // TILE
+            trail += (t * (t + 1) // 2) * TILE * TILE * 2.0 * w
+            n_trail += 1
+        j0 += W
+    return trail, n_trail, strip, n_strip
+
+
+def cpu_baseline(args, np_dtype, eps):
+    """The CPU oracle (NumPy/SciPy port of the same math) on a bounded sample of the workload."""
+    import scipy.linalg as sla
+    from oracle import nngp_oracle as O
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([i.get("num_threads", 1) for i in threadpool_info()] or [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    ns = min(args.cpu_sample_n, args.n)
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((ns, args.d)).astype(np_dtype)
+    y = rng.standard_normal(ns).astype(np_dtype)
+    t0 = time.perf_counter()
+    k = O.mlp_kernel(x, None, args.layers, args.act, 1.0, 1e-8, 1.0, "nngp", np_dtype)
+    t1 = time.perf_counter()
+    k[np.diag_indices(ns)] += np_dtype(eps)
+    l = sla.cholesky(k, lower=True, overwrite_a=True, check_finite=False)
+    z = sla.solve_triangular(l, y, lower=True, check_finite=False)
+    lp = -0.5 * float(z @ z) - ns / 2 * np.log(2 * np.pi) - float(np.log(np.diag(l)).sum())
+    t2 = time.perf_counter()
+    flops = 2.0 * ns * ns * args.d + ns ** 3 / 3.0
+    return {
+        "value": flops / (t2 - t0) / 1e9, "unit": "GFLOP/s", "cores": int(threads), "kind": "port",
+        "sample": "same workload at N=%d (d=%d, L=%d %s, %s): NumPy/SciPy oracle, build %.2f s + Cholesky/LML %.2f s"
+                  % (ns, args.d, args.layers, args.act, np.dtype(np_dtype).name, t1 - t0, t2 - t1),
+        "logpdf_finite": bool(np.isfinite(lp)),
+    }
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+        args.gpus = world
+
+    from smnngp import _lib as L
+
+    np_dtype = np.float32 if args.dtype == "f32" else np.float64
+    code = L.dtype_code(np_dtype)
+    eps = args.eps if args.eps is not None else (1e-3 if args.dtype == "f32" else 1e-6)
+    act = L.ACT[args.act]
+    n, d, nl = args.n, args.d, args.layers
+    ctx = L.Context(local_rank)
+
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        dist.init_process_group("gloo")            # host-side rendezvous only; the data path is RCCL below
+        uid = C.create_string_buffer(128)
+        if rank == 0:
+            assert L._lib.smn_comm_unique_id(uid) == 0, "RCCL unavailable"
+        t = torch.tensor(list(uid.raw), dtype=torch.uint8)
+        dist.broadcast(t, 0)
+        uid = C.create_string_buffer(bytes(t.tolist()), 128)
+        ctx.call("smn_comm_init", world, rank, uid)
+
+    rng = np.random.default_rng(0)                 # same seed on every rank: X is replicated
+    x = ctx.to_device(rng.standard_normal((n, d)).astype(np_dtype))
+    y = ctx.to_device(rng.standard_normal(n).astype(np_dtype))
+    lp, quad, logdet, info = C.c_double(), C.c_double(), C.c_double(), C.c_int()
+
+    if world == 1:
+        def step():
+            ctx.call("smn_spr_loss", code, L.NET_MLP, act, nl, 1.0, 1e-8, 1.0, x.ptr, n, d, d, y.ptr, eps, 0.0, 1.0,
+                     C.byref(lp), C.byref(quad), C.byref(logdet), C.byref(info))
+    else:
+        if n % world:
+            sys.exit("N must be divisible by the number of ranks")
+        rows = n // world
+        kfull = ctx.empty((n, n), np_dtype)
+        es = np.dtype(np_dtype).itemsize
+        mine = C.c_void_p(kfull.ptr.value + rank * rows * n * es)
+
+        def step():
+            ctx.call("smn_kernel_mlp_rows", code, L.NET_MLP, act, nl, 1.0, 1e-8, 1.0, x.ptr, n, d, d,
+                     rank * rows, (rank + 1) * rows, L.GET_NNGP, mine, None, n)
+            ctx.call("smn_allgather", code, mine, kfull.ptr, rows * n)
+            ctx.call("smn_lml", code, kfull.ptr, n, n, y.ptr, eps, 0.0, 1.0, C.byref(lp), C.byref(quad),
+                     C.byref(logdet), C.byref(info))
+
+    def barrier():
+        ctx.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ctx.call("smn_profile_enable", 1)              # hipEvent pairs around every launch of the timed region
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = {}
+    for cat, name in enumerate(["prep", "build", "recursion", "panel", "strip", "trail", "misc"]):
+        ms, cnt = C.c_double(), C.c_int()
+        ctx.call("smn_profile_read", cat, C.byref(ms), C.byref(cnt))
+        prof[name] = (ms.value, cnt.value)
+    ctx.call("smn_profile_enable", 0)
+    if dist is not None:
+        import torch
+        tt = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    ms_per_step = dt / args.steps * 1e3
+
+    if rank == 0:
+        n_total = n + TILE if world == 1 else n + TILE
+        flops_counted = 2.0 * n * n * d + n ** 3 / 3.0                 # Gram 2N^2 d + Cholesky N^3/3
+        trail_fl, n_trail, strip_fl, n_strip = cholesky_launch_model(n_total, n)
+        peak = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_F64_MFMA_TFLOPS
+        per = {k: (v[0] / max(args.steps, 1), v[1] // max(args.steps, 1)) for k, v in prof.items()}
+        kp = ((d + 31) // 32 * 32) if args.dtype == "f32" else ((d + 15) // 16 * 16)
+        if world == 1:
+            t = n_total // TILE
+            build_fl = (t * (t + 1) // 2) * TILE * TILE * 2.0 * kp
+        else:
+            build_fl = ((n // world + TILE - 1) // TILE) * (n // TILE) * TILE * TILE * 2.0 * kp
+        trail_ms = per["trail"][0]
+        roof = {
+            "kernel": "update_kernel<%s,1> (Cholesky trailing update C -= P P^T, K=256, lower 128x128 tiles)" % (
+                "float" if args.dtype == "f32" else "double"),
+            "bound": "mfma",
+            "achieved": trail_fl / (trail_ms * 1e-3) / 1e12 if trail_ms > 0 else None,
+            "peak": peak, "unit": "TFLOP/s",
+            "frac": (trail_fl / (trail_ms * 1e-3) / 1e12 / peak) if trail_ms > 0 else None,
+            "traffic": None,
+            "launches_per_step": per["trail"][1], "avg_launch_ms": trail_ms / max(per["trail"][1], 1),
+            "flops_per_step": trail_fl,
+        }
+        others = {}
+        if per["build"][0] > 0:
+            others["build_kernel (fused Gram + %d-layer recursion, executed tiles)" % nl] = {
+                "bound": "mfma", "achieved": build_fl / (per["build"][0] * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
+                "frac": build_fl / (per["build"][0] * 1e-3) / 1e12 / peak, "ms": per["build"][0]}
+        out = {
+            "metric": "kernel-build + Cholesky wallclock (ms) and GFLOP/s at N=%d, %d-layer %s NNGP" % (n, nl, args.act),
+            "value": flops_counted / (ms_per_step * 1e-3) / 1e9, "unit": "GFLOP/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "SPR.loss: NNGP kernel build + jittered Cholesky + Gaussian LML, N=%d d=%d L=%d %s"
+                                   % (n, d, nl, args.act),
+                       "N": n, "d": d, "layers": nl, "act": args.act, "w_std": 1.0, "b_std": 1e-8, "last_w_std": 1.0,
+                       "eps_abs": eps, "flops_counted": flops_counted,
+                       "parallelism": "single GPU" if world == 1 else "row-sharded build x%d + RCCL all-gather + replicated Cholesky" % world},
+            "phases_ms": {k: round(v[0], 4) for k, v in per.items()},
+            "result": {"logpdf": lp.value, "logdet": logdet.value, "info": info.value},
+            "roofline": roof,
+        }
+        # stand-alone recursion (a3): HBM roofline probe on a stored K0, outside the timed region
+        if world == 1 and not args.no_recursion_probe:
+            try:
+                k0 = ctx.empty((n, n), np_dtype); kk = ctx.empty((n, n), np_dtype)
+                q1 = ctx.empty((n,), np_dtype)
+                ctx.call("smn_gram", code, x.ptr, n, d, None, 0, 0, d, k0.ptr, n, q1.ptr, None)
+                for _ in range(2):
+                    ctx.call("smn_recursion", code, L.NET_MLP, act, nl, 1.0, 1e-8, 1.0, k0.ptr, n, n, n, q1.ptr, q1.ptr,
+                             1, L.GET_NNGP, kk.ptr, None, n)
+                ctx.call("smn_profile_enable", 1)
+                reps = 5
+                for _ in range(reps):
+                    ctx.call("smn_recursion", code, L.NET_MLP, act, nl, 1.0, 1e-8, 1.0, k0.ptr, n, n, n, q1.ptr, q1.ptr,
+                             1, L.GET_NNGP, kk.ptr, None, n)
+                ms, cnt = C.c_double(), C.c_int()
+                ctx.call("smn_profile_read", 2, C.byref(ms), C.byref(cnt))
+                ctx.call("smn_profile_enable", 0)
+                rec_ms = ms.value / max(cnt.value, 1)
+                nbytes = 2.0 * n * n * np.dtype(np_dtype).itemsize
+                others["recursion_kernel (stand-alone %d-layer %s map over a stored K0)" % (nl, args.act)] = {
+                    "bound": "hbm", "achieved": nbytes / (rec_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                    "frac": nbytes / (rec_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "ms": rec_ms}
+                del k0, kk
+            except Exception as e:  # the probe must never break the bench line
+                others["recursion_kernel"] = {"error": str(e)}
+        out["roofline_other_kernels"] = others
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args, np_dtype, eps)
+        elif world == 1:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        ctx.call("smn_comm_destroy")
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

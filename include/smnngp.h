@@ -59,6 +59,11 @@ int smn_memcpy2d_d2h(smn_ctx* ctx, void* dst_h, size_t dpitch, const void* src_d
 /* timing hooks (hipEvents on the context's stream) */
 int smn_timer_start(smn_ctx* ctx);
 int smn_timer_stop_ms(smn_ctx* ctx, double* ms);           /* synchronises */
+/* per-kernel timing: while enabled every kernel launch is bracketed by a hipEvent pair on its own
+ * stream.  category: 0 prep (pad/tables), 1 fused Gram+recursion build, 2 stand-alone recursion,
+ * 3 Cholesky panel, 4 Cholesky strip update, 5 Cholesky trailing update, 6 other. */
+int smn_profile_enable(smn_ctx* ctx, int on);
+int smn_profile_read(smn_ctx* ctx, int category, double* total_ms, int* launches);
 
 /* ---- NNGP / NTK kernel build ----
  * Replaces kernel_fn(x1, x2, get) produced by get_mlp_kernel / get_dense_resnet_kernel

@@ -121,6 +121,15 @@ def _dense(k, q1, q2, theta, w, b):
     return k, q1, q2, theta
 
 
+def _fix_diag(k, q, sym):
+    """Symmetric case: the diagonal of K IS the variance recursion q.  Forcing it removes the
+    sqrt(rounding) noise that K_ii / sqrt(q_i q_i) = 1 - 1e-16 injects into acos at c = 1 (the generic
+    formula loses half the digits there; at fp64 that shows up as ~1e-9 on K_ii and ~1e-6 on Kdot_ii
+    after two layers).  The restated math is unchanged; only its evaluation at c = 1 is made exact."""
+    if sym:
+        np.fill_diagonal(k, q)
+
+
 def _ret(k, theta, get):
     if get == "nngp":
         return k
@@ -137,12 +146,17 @@ def mlp_kernel(x1, x2=None, num_hiddens=1, act="relu", w_std=1.0, b_std=0.0,
     amap = get_act(act)
     x1 = np.asarray(x1, dtype=dtype)
     x2 = None if x2 is None else np.asarray(x2, dtype=dtype)
+    sym = x2 is None
     k, q1, q2 = input_gram(x1, x2)
+    _fix_diag(k, q1, sym)
     theta = None if get == "nngp" else np.zeros_like(k)
     for _ in range(num_hiddens):
         k, q1, q2, theta = _dense(k, q1, q2, theta, w_std, b_std)
+        _fix_diag(k, q1, sym)
         k, q1, q2, theta = amap(k, q1, q2, theta)
+        _fix_diag(k, q1, sym)
     k, q1, q2, theta = _dense(k, q1, q2, theta, last_w_std, 0.0)
+    _fix_diag(k, q1, sym)
     return _ret(k, theta, get)
 
 
@@ -166,17 +180,21 @@ def dense_resnet_kernel(x1, x2=None, num_hiddens=1, act="relu", w_std=1.0, b_std
     amap = get_act(act)
     x1 = np.asarray(x1, dtype=dtype)
     x2 = None if x2 is None else np.asarray(x2, dtype=dtype)
+    sym = x2 is None
     k, q1, q2 = input_gram(x1, x2)
     theta = None if get == "nngp" else np.zeros_like(k)
     k, q1, q2, theta = _dense(k, q1, q2, theta, w_std, b_std)
+    _fix_diag(k, q1, sym)
     for _ in range(num_hiddens):
         kb, q1b, q2b, tb = amap(k, q1, q2, theta)
         kb, q1b, q2b, tb = _dense(kb, q1b, q2b, tb, w_std, b_std)
         k, q1, q2 = kb + k, q1b + q1, q2b + q2
+        _fix_diag(k, q1, sym)
         if theta is not None:
             theta = tb + theta
     k, q1, q2, theta = amap(k, q1, q2, theta)
     k, q1, q2, theta = _dense(k, q1, q2, theta, last_w_std, 0.0)
+    _fix_diag(k, q1, sym)
     return _ret(k, theta, get)
 
 

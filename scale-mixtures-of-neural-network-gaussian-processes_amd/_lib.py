@@ -59,6 +59,8 @@ PROTOTYPES = {
     "smn_memcpy2d_d2h": [_vp, _vp, _sz, _vp, _sz, _sz, _sz],
     "smn_timer_start": [_vp],
     "smn_timer_stop_ms": [_vp, _pd],
+    "smn_profile_enable": [_vp, _i],
+    "smn_profile_read": [_vp, _i, _pd, _pi],
     "smn_kernel_mlp": [_vp, _i, _i, _i, _i, _d, _d, _d, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _i, _i, _vp, _vp, _i64],
     "smn_kernel_mlp_rows": [_vp, _i, _i, _i, _i, _d, _d, _d, _vp, _i64, _i64, _i64, _i64, _i64, _i, _vp, _vp, _i64],
     "smn_gram": [_vp, _i, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _vp, _vp],

@@ -183,6 +183,7 @@ extern "C" int smn_ctx_destroy(smn_ctx* c) {
   if (c->comm) smn_comm_destroy(c);
   for (int i = 0; i < 4; ++i)
     if (c->ws[i]) (void)hipFree(c->ws[i]);
+  for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
   if (c->d_scal) (void)hipFree(c->d_scal);
   if (c->d_info) (void)hipFree(c->d_info);
   if (c->ev_a) (void)hipEventDestroy(c->ev_a);
@@ -278,5 +279,33 @@ extern "C" int smn_timer_stop_ms(smn_ctx* ctx, double* ms) {
   float f = 0.f;
   SMN_HIP(ctx, hipEventElapsedTime(&f, ctx->ev_t0, ctx->ev_t1));
   *ms = (double)f;
+  return SMN_OK;
+}
+
+// ---- per-kernel timing hooks (bench.py's roofline numbers come from these hipEvents) ----
+extern "C" int smn_profile_enable(smn_ctx* ctx, int on) {
+  if (!ctx) return SMN_EINVAL;
+  SMN_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->prof = on != 0;
+  ctx->prof_used = 0;
+  ctx->prof_cat.clear();
+  return SMN_OK;
+}
+
+extern "C" int smn_profile_read(smn_ctx* ctx, int category, double* total_ms, int* launches) {
+  if (!ctx || category < 0 || category >= PROF_NCAT) return SMN_EINVAL;
+  SMN_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  double tot = 0.0;
+  int cnt = 0;
+  for (size_t i = 0; i < ctx->prof_cat.size() && 2 * i + 1 < ctx->prof_used + 1; ++i) {
+    if (ctx->prof_cat[i] != category) continue;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, ctx->prof_ev[2 * i], ctx->prof_ev[2 * i + 1]) == hipSuccess) {
+      tot += ms;
+      ++cnt;
+    }
+  }
+  if (total_ms) *total_ms = tot;
+  if (launches) *launches = cnt;
   return SMN_OK;
 }

@@ -133,7 +133,9 @@ struct UpdArgs {
   T* a; int64_t lda; int64_t r0, c0, k0; int K; int tiles_n; int lower;
 };
 
-template <typename T>
+// TAG only separates the two uses into two symbols (0: strip update, 1: trailing update) so that
+// rocprofv3 --stats reports them on separate lines.
+template <typename T, int TAG>
 __global__ void __launch_bounds__(256, sizeof(T) == 8 ? 1 : 2) update_kernel(UpdArgs<T> u) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using Tile = TileNT<T, kTile, kTile>;
@@ -199,9 +201,17 @@ int launch_update(smn_ctx* ctx, hipStream_t st, T* a, int64_t lda, int64_t r0, i
   if (tiles_m <= 0 || tiles_n <= 0 || K <= 0) return SMN_OK;
   UpdArgs<T> u{a, lda, r0, c0, k0, K, (int)tiles_n, lower};
   const int64_t nt = lower ? tiles_m * (tiles_m + 1) / 2 : tiles_m * tiles_n;
-  auto kern = update_kernel<T>;
   const size_t lds = TileNT<T, kTile, kTile>::LDS_BYTES;
-  hipLaunchKernelGGL(kern, dim3((unsigned)nt), dim3(256), lds, st, u);
+  {
+    ProfScope ps(ctx, lower ? PROF_TRAIL : PROF_STRIP, st);
+    if (lower) {
+      auto kern = update_kernel<T, 1>;
+      hipLaunchKernelGGL(kern, dim3((unsigned)nt), dim3(256), lds, st, u);
+    } else {
+      auto kern = update_kernel<T, 0>;
+      hipLaunchKernelGGL(kern, dim3((unsigned)nt), dim3(256), lds, st, u);
+    }
+  }
   SMN_CHECK_LAUNCH(ctx);
   return SMN_OK;
 }
@@ -214,8 +224,11 @@ int launch_panel(smn_ctx* ctx, hipStream_t st, T* a, int64_t lda, int64_t j0, in
   const unsigned grid = below > 0 ? (unsigned)((below + XR - 1) / XR) : 1u;
   const size_t lds = sizeof(T) * (size_t)(PB + XR) * (PB + 1);
   auto kern = panel_kernel<T>;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(PanelCfg<T>::THREADS), lds, st, a, lda, j0, rbeg, n_total, prefactored,
-                     ctx->d_scal, ctx->d_info);
+  {
+    ProfScope ps(ctx, PROF_PANEL, st);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(PanelCfg<T>::THREADS), lds, st, a, lda, j0, rbeg, n_total, prefactored,
+                       ctx->d_scal, ctx->d_info);
+  }
   SMN_CHECK_LAUNCH(ctx);
   return SMN_OK;
 }
@@ -227,7 +240,10 @@ int set_lds_attrs(smn_ctx* ctx) {
   SMN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(panel_kernel<T>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)(sizeof(T) * (PB + PanelCfg<T>::XR) * (PB + 1))));
-  SMN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(update_kernel<T>),
+  SMN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(update_kernel<T, 0>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)TileNT<T, kTile, kTile>::LDS_BYTES));
+  SMN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(update_kernel<T, 1>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)TileNT<T, kTile, kTile>::LDS_BYTES));
   done = true;

@@ -26,6 +26,36 @@ struct smn_ctx {
   int* d_info = nullptr;      // 16 ints
   void* comm = nullptr;       // ncclComm_t when smn_comm_init was called
   int nranks = 1, rank = 0;
+  // per-kernel timing (smn_profile_*): hipEvent pairs around launches, resolved on read
+  bool prof = false;
+  std::vector<hipEvent_t> prof_ev;   // pool, used pairwise
+  std::vector<int> prof_cat;         // category of pair i
+  size_t prof_used = 0;              // events handed out
+};
+
+enum { PROF_PREP = 0, PROF_BUILD = 1, PROF_RECURSION = 2, PROF_PANEL = 3, PROF_STRIP = 4, PROF_TRAIL = 5,
+       PROF_MISC = 6, PROF_NCAT = 7 };
+
+// Brackets the launches issued during its lifetime with an event pair when profiling is on.
+struct ProfScope {
+  smn_ctx* c; hipStream_t st; bool on;
+  ProfScope(smn_ctx* ctx, int cat, hipStream_t stream) : c(ctx), st(stream), on(ctx->prof) {
+    if (!on) return;
+    if (c->prof_used + 2 > c->prof_ev.size()) {
+      for (int i = 0; i < 256; ++i) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) { on = false; return; }
+        c->prof_ev.push_back(e);
+      }
+    }
+    c->prof_cat.push_back(cat);
+    (void)hipEventRecord(c->prof_ev[c->prof_used], st);
+  }
+  ~ProfScope() {
+    if (!on) return;
+    (void)hipEventRecord(c->prof_ev[c->prof_used + 1], st);
+    c->prof_used += 2;
+  }
 };
 
 inline int smn_fail(smn_ctx* ctx, int code, const char* fmt, ...) {

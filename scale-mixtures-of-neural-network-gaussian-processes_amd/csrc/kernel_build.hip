@@ -34,33 +34,50 @@ __global__ void pad_rows_kernel(const T* __restrict__ src, int64_t n, int64_t ld
   if (lane == 0 && q) q[row] = s * inv_d;
 }
 
-// Per-row tables.  tab[(set*2+0)*ldt + i] = r, tab[(set*2+1)*ldt + i] = s, dg[i] = final diagonal.
+// Per-row tables.  tab[(set*2+0)*ldt + i] = r, tab[(set*2+1)*ldt + i] = s; dg[i] / dgt[i] = the
+// closed-form NNGP / NTK diagonal (c = 1: ReLU Kdot = 1/2, erf Kdot = 4 / (pi sqrt(1 + 4q))).
 template <typename T>
 __global__ void diag_tables_kernel(const double* __restrict__ q0, int64_t n, LayerProg p,
-                                   T* __restrict__ tab, int64_t ldt, T* __restrict__ dg) {
+                                   T* __restrict__ tab, int64_t ldt, T* __restrict__ dg, T* __restrict__ dgt) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  double q = q0[i];
-  if (p.net == NET_RESNET) q = p.w2 * q + p.b2;
+  double q = q0[i], th = 0.0;
+  if (p.net == NET_RESNET) {
+    q = p.w2 * q + p.b2;
+    th = q;
+  }
   for (int s = 0; s < p.nsets; ++s) {
-    double qt = (p.net == NET_MLP) ? p.w2 * q + p.b2 : q;   // pre-activation variance
-    double r, sv, qa;
+    const double qt = (p.net == NET_MLP) ? p.w2 * q + p.b2 : q;   // pre-activation variance
+    const double tht = (p.net == NET_MLP) ? qt + p.w2 * th : th;
+    double r, sv, qa, kdot;
     if (p.act == ACT_RELU) {
       r = qt > 0.0 ? 1.0 / sqrt(qt) : 0.0;
       sv = sqrt(qt / (2.0 * nngp::kPi));
       qa = 0.5 * qt;
+      kdot = 0.5;
     } else {
       r = 1.0 / sqrt(1.0 + 2.0 * qt);
       sv = 0.0;
       qa = (2.0 / nngp::kPi) * asin(2.0 * qt / (1.0 + 2.0 * qt));
+      kdot = 4.0 / (nngp::kPi * sqrt(1.0 + 4.0 * qt));
     }
     tab[(int64_t)(2 * s) * ldt + i] = (T)r;
     tab[(int64_t)(2 * s + 1) * ldt + i] = (T)sv;
-    if (p.net == NET_MLP || s == p.nsets - 1) q = qa;
-    else q = q + p.w2 * qa + p.b2;
+    if (p.net == NET_MLP || s == p.nsets - 1) {
+      q = qa;
+      th = tht * kdot;
+    } else {
+      const double ka = p.w2 * qa + p.b2;
+      th += ka + p.w2 * (tht * kdot);
+      q += ka;
+    }
   }
-  if (p.net != NET_NONE) q *= p.lw2;
+  if (p.net != NET_NONE) {
+    q *= p.lw2;
+    th = q + p.lw2 * th;
+  }
   dg[i] = (T)q;
+  dgt[i] = (T)th;
 }
 
 // ------------------------------------------------------------------ fused Gram + recursion
@@ -68,7 +85,7 @@ template <typename T>
 struct BuildArgs {
   const T* x1; const T* x2; int64_t ld1, ld2; int kp;
   int tiles_n; int symmetric; int mirror;
-  const T* tab1; const T* tab2; int64_t ldt1, ldt2; const T* dg;
+  const T* tab1; const T* tab2; int64_t ldt1, ldt2; const T* dg; const T* dgt;
   T inv_d; LayerProg prog;
   int64_t row_off, col_off; int exact_diag;
   int store_mode; int64_t out_rows, out_cols; int64_t nv0, aug0, nv1;
@@ -158,7 +175,10 @@ __global__ void __launch_bounds__(256, (NTK || sizeof(T) == 8) ? 1 : 2) build_ke
         const int64_t gc = col0 + wc * Tile::WN + n * M::TN + M::acc_col(lane);
         T k = t.acc[m][n][i], h = th[m][n][i];
         prog.post(k, h);
-        if (a.exact_diag && gr + a.row_off == gc + a.col_off) k = a.dg[gr];
+        if (a.exact_diag && gr + a.row_off == gc + a.col_off) {
+          k = a.dg[gr];
+          if (NTK) h = a.dgt[gr];
+        }
         bool wr_ok;
         if (a.store_mode == STORE_PAD_IDENTITY) {
           const bool vr = gr < a.nv0 || (gr >= a.aug0 && gr < a.aug0 + a.nv1);
@@ -186,7 +206,7 @@ __global__ void __launch_bounds__(256, (NTK || sizeof(T) == 8) ? 1 : 2) build_ke
 template <typename T>
 struct RecArgs {
   const T* k0; int64_t ldk0; int64_t n1, n2;
-  const T* tab1; const T* tab2; int64_t ldt1, ldt2; const T* dg;
+  const T* tab1; const T* tab2; int64_t ldt1, ldt2; const T* dg; const T* dgt;
   LayerProg prog; int exact_diag;
   T* out_k; T* out_t; int64_t ldo; int rows_per_block;
 };
@@ -249,7 +269,10 @@ __global__ void __launch_bounds__(256) recursion_kernel(RecArgs<T> a) {
     for (int e = 0; e < VEC; ++e) {
       T k = kv[e], h = hv[e];
       prog.post(k, h);
-      if (a.exact_diag && row == gc + e) k = a.dg[row];
+      if (a.exact_diag && row == gc + e) {
+        k = a.dg[row];
+        if (NTK) h = a.dgt[row];
+      }
       kv[e] = k;
       hv[e] = h;
     }
@@ -289,7 +312,10 @@ int launch_build_t(smn_ctx* ctx, const BuildArgs<T>& a, int64_t ntiles, size_t l
   auto kern = build_kernel<T, NET, ACT, NTK>;
   SMN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kern, dim3((unsigned)ntiles), dim3(256), lds, ctx->stream, a);
+  {
+    ProfScope ps(ctx, PROF_BUILD, ctx->stream);
+    hipLaunchKernelGGL(kern, dim3((unsigned)ntiles), dim3(256), lds, ctx->stream, a);
+  }
   SMN_CHECK_LAUNCH(ctx);
   return SMN_OK;
 }
@@ -319,20 +345,21 @@ int run_build_t(smn_ctx* ctx, const BuildCall& c) {
   const bool ntk = (c.get_mask & SMN_GET_NTK) != 0;
   if (ntk && prog.net == NET_NONE) return smn_fail(ctx, SMN_EINVAL, "NTK of a bare Gram");
   // tables: [2*nsets + 1] rows of length rows1 (+ rows2 when not symmetric)
-  const int trows = 2 * prog.nsets + 1;
+  const int trows = 2 * prog.nsets + 2;
   const int64_t tlen = c.symmetric ? c.rows1 : c.rows1 + c.rows2;
   void* tabv = nullptr;
   SMN_TRY(smn_workspace(ctx, 1, sizeof(T) * (size_t)trows * (size_t)tlen, &tabv));
   T* tab1 = static_cast<T*>(tabv);
   T* dg1 = tab1 + (int64_t)(2 * prog.nsets) * tlen;
+  T* dgt1 = dg1 + tlen;
   hipLaunchKernelGGL(diag_tables_kernel<T>, dim3((unsigned)((c.rows1 + 255) / 256)), dim3(256), 0, ctx->stream,
-                     c.q1, c.rows1, prog, tab1, tlen, dg1);
+                     c.q1, c.rows1, prog, tab1, tlen, dg1, dgt1);
   SMN_CHECK_LAUNCH(ctx);
   T* tab2 = tab1;
   if (!c.symmetric) {
     tab2 = tab1 + c.rows1;
     hipLaunchKernelGGL(diag_tables_kernel<T>, dim3((unsigned)((c.rows2 + 255) / 256)), dim3(256), 0, ctx->stream,
-                       c.q2, c.rows2, prog, tab2, tlen, dg1 + c.rows1);
+                       c.q2, c.rows2, prog, tab2, tlen, dg1 + c.rows1, dgt1 + c.rows1);
     SMN_CHECK_LAUNCH(ctx);
   }
   BuildArgs<T> a;
@@ -340,7 +367,7 @@ int run_build_t(smn_ctx* ctx, const BuildCall& c) {
   a.ld1 = c.ld1; a.ld2 = c.ld2; a.kp = c.kp;
   const int64_t tm = c.rows1 / kTile, tn = c.rows2 / kTile;
   a.tiles_n = (int)tn; a.symmetric = c.symmetric; a.mirror = c.mirror;
-  a.tab1 = tab1; a.tab2 = tab2; a.ldt1 = tlen; a.ldt2 = tlen; a.dg = dg1;
+  a.tab1 = tab1; a.tab2 = tab2; a.ldt1 = tlen; a.ldt2 = tlen; a.dg = dg1; a.dgt = dgt1;
   a.inv_d = (T)(1.0 / (double)c.d); a.prog = prog;
   a.row_off = c.row_off; a.col_off = c.col_off; a.exact_diag = c.exact_diag;
   a.store_mode = c.store_mode; a.out_rows = c.out_rows; a.out_cols = c.out_cols;
@@ -357,7 +384,10 @@ int run_build_t(smn_ctx* ctx, const BuildCall& c) {
 
 template <typename T, int NET, int ACT, bool NTK>
 int launch_rec_t(smn_ctx* ctx, const RecArgs<T>& a, dim3 grid, size_t lds) {
-  hipLaunchKernelGGL((recursion_kernel<T, NET, ACT, NTK>), grid, dim3(256), lds, ctx->stream, a);
+  {
+    ProfScope ps(ctx, PROF_RECURSION, ctx->stream);
+    hipLaunchKernelGGL((recursion_kernel<T, NET, ACT, NTK>), grid, dim3(256), lds, ctx->stream, a);
+  }
   SMN_CHECK_LAUNCH(ctx);
   return SMN_OK;
 }
@@ -394,25 +424,26 @@ int recursion_t(smn_ctx* ctx, const BuildSpec& spec, const void* k0, int64_t n1,
   SMN_TRY(make_prog(ctx, spec, &prog));
   if (prog.net == NET_NONE) return smn_fail(ctx, SMN_EINVAL, "recursion needs a net");
   const bool want_ntk = (get_mask & SMN_GET_NTK) != 0;
-  const int trows = 2 * prog.nsets + 1;
+  const int trows = 2 * prog.nsets + 2;
   const int64_t tlen = n1 + n2;
   void* tabv = nullptr;
   SMN_TRY(smn_workspace(ctx, 1, sizeof(T) * (size_t)trows * tlen + sizeof(double) * (size_t)tlen, &tabv));
   double* qd = static_cast<double*>(tabv);
   T* tab1 = reinterpret_cast<T*>(qd + tlen);
   T* dg1 = tab1 + (int64_t)(2 * prog.nsets) * tlen;
+  T* dgt1 = dg1 + tlen;
   hipLaunchKernelGGL(cast_to_double_kernel<T>, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, ctx->stream,
                      static_cast<const T*>(q1), qd, n1, n1);
   hipLaunchKernelGGL(cast_to_double_kernel<T>, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, ctx->stream,
                      static_cast<const T*>(q2), qd + n1, n2, n2);
   hipLaunchKernelGGL(diag_tables_kernel<T>, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, ctx->stream,
-                     qd, n1, prog, tab1, tlen, dg1);
+                     qd, n1, prog, tab1, tlen, dg1, dgt1);
   hipLaunchKernelGGL(diag_tables_kernel<T>, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, ctx->stream,
-                     qd + n1, n2, prog, tab1 + n1, tlen, dg1 + n1);
+                     qd + n1, n2, prog, tab1 + n1, tlen, dg1 + n1, dgt1 + n1);
   SMN_CHECK_LAUNCH(ctx);
   RecArgs<T> a;
   a.k0 = static_cast<const T*>(k0); a.ldk0 = ldk0; a.n1 = n1; a.n2 = n2;
-  a.tab1 = tab1; a.tab2 = tab1 + n1; a.ldt1 = tlen; a.ldt2 = tlen; a.dg = dg1;
+  a.tab1 = tab1; a.tab2 = tab1 + n1; a.ldt1 = tlen; a.ldt2 = tlen; a.dg = dg1; a.dgt = dgt1;
   a.prog = prog; a.exact_diag = symmetric;
   a.out_k = (get_mask & SMN_GET_NNGP) ? static_cast<T*>(nngp) : nullptr;
   a.out_t = want_ntk ? static_cast<T*>(ntk) : nullptr;
@@ -432,6 +463,7 @@ int recursion_t(smn_ctx* ctx, const BuildSpec& spec, const void* k0, int64_t n1,
 int pad_rows(smn_ctx* ctx, int dtype, const void* src, int64_t n, int64_t lds, int64_t d,
              void* dst, int64_t rows_pad, int64_t kp, double* q) {
   const unsigned blocks = (unsigned)((rows_pad + 3) / 4);
+  ProfScope ps(ctx, PROF_PREP, ctx->stream);
   if (dtype == SMN_F64)
     hipLaunchKernelGGL(pad_rows_kernel<double>, dim3(blocks), dim3(256), 0, ctx->stream, static_cast<const double*>(src),
                        n, lds, d, static_cast<double*>(dst), rows_pad, kp, 1.0 / (double)d, q);

@@ -5,6 +5,7 @@ import math
 
 import numpy as np
 
+from .._lib import as_device
 from .base import ConstraintTrainVar, Module
 from .bijectors import positive
 from .utils import factor_stats, jitter, multivariate_normal_logpdf, multivariate_t_logpdf
@@ -78,6 +79,9 @@ class StudentTLikelihood(Likelihood):
         if isinstance(cov_data, float):
             quad = cov_data
         else:
+            if getattr(cov_data, "dtype", None) == np.float32:
+                # 1e-6 jitter is below fp32 resolution of an O(1) kernel: factor this one in fp64
+                cov_data = as_device(np.asarray(cov_data, dtype=np.float64))
             quad, _, _ = factor_stats(y_data, (b / a) * cov_data + jitter(num_data))
         d = df + quad
         sigma = np.sqrt(np.diagonal(d / cond_df * b / a * np.asarray(cov, dtype=np.float64)))

@@ -29,6 +29,15 @@ class SPR(Module):
         self.num_data = self.x_data.shape[0]
         self.eps = ConstraintTrainVar(eps, constraint=positive())
 
+    def _f64_data(self):
+        if self.x_data.dtype == np.float64:
+            return self.x_data, self.y_data
+        if getattr(self, "_x64", None) is None:
+            ctx = self.x_data.ctx
+            self._x64 = ctx.to_device(self.x_data.numpy().astype(np.float64))
+            self._y64 = ctx.to_device(self.y_host)
+        return self._x64, self._y64
+
     # ---- spax/models.py:93-98
     def loss(self):
         eps = self.eps.safe_value
@@ -58,12 +67,16 @@ class SPR(Module):
                 if isinstance(kernel_fn, KernelFn):
                     # likelihoods.py:60-61 needs y^T (b/a K + 1e-6 I)^-1 y with K WITHOUT the eps jitter
                     # (models.py:107 "TODO: check"); hand the quadratic form over instead of an N x N matrix.
+                    # That matrix carries only a 1e-6 jitter: in fp32 it is not numerically PD (the
+                    # reference's fp32 inv() returns noise there), so this one quadratic form always runs
+                    # in fp64 on upcast copies of the training data.
                     _, scale = self.likelihood.lml_params()
-                    xd, ctx = self.x_data, self.x_data.ctx
+                    xd, yd = self._f64_data()
+                    ctx = xd.ctx
                     net, act, L, w, b, lw = kernel_fn.params
                     quad, info = C.c_double(), C.c_int()
                     ctx.call("smn_spr_loss", xd.dcode, net, act, L, w, b, lw, xd.ptr, xd.shape[0], xd.shape[1],
-                             xd.shape[1], self.y_data.ptr, 1e-6 / scale, 0.0, 1.0, None, C.byref(quad), None,
+                             xd.shape[1], yd.ptr, 1e-6 / scale, 0.0, 1.0, None, C.byref(quad), None,
                              C.byref(info))
                     cov_data = float("nan") if info.value else quad.value / scale
                 else:

@@ -263,15 +263,18 @@ def test_spr_loss_and_test_nll(dtype, method, network):
     rl = O.spr_loss(xtr, ytr, **okw)
     rn = O.spr_test_nll(xtr, ytr, xte, yte, ym, ys, **okw)
     tol = 1e-7 if dtype == np.float64 else 1e-2
+    # Student-t test_nll holds y^T (b/a K + 1e-6 I)^-1 y (likelihoods.py:60): cond ~1e9 here, so two
+    # correct fp64 factorizations differ at ~1e-6; the north-star bar for fp64 is 1e-5.
+    tol_nll = 1e-5 if (dtype == np.float64 and method == "tp") else tol
     assert abs(model.loss() - rl) < tol * max(1.0, abs(rl))
-    assert abs(model.test_nll(xte.astype(dtype), yte.astype(dtype)) - rn) < tol * max(1.0, abs(rn))
+    assert abs(model.test_nll(xte.astype(dtype), yte.astype(dtype)) - rn) < tol_nll * max(1.0, abs(rn))
     # trainables round-trip through the softplus constraint (spax/base.py:15-25)
     assert abs(kernel.w_std.safe_value - ws) < 1e-12 and abs(model.eps.safe_value - eps) < 1e-12
     # the un-fused path (generic kernel_fn -> K + jitter -> prior_logpdf) gives the same number
     kernel2 = NNGPKernel(lambda w, b, l: (lambda a, c, get: get_kernel_fn(w, b, l)(a, c, get)), ws, bs, ls)
     model2 = SPR(kernel2, lik, xtr.astype(dtype), ytr.astype(dtype), ym, ys, eps=eps)
     assert abs(model2.loss() - rl) < tol * max(1.0, abs(rl))
-    assert abs(model2.test_nll(xte.astype(dtype), yte.astype(dtype)) - rn) < tol * max(1.0, abs(rn))
+    assert abs(model2.test_nll(xte.astype(dtype), yte.astype(dtype)) - rn) < tol_nll * max(1.0, abs(rn))
 
 
 def test_not_pd_gives_nan_like_the_reference():
