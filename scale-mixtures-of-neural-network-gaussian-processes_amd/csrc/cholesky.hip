@@ -26,6 +26,7 @@
 namespace {
 
 constexpr int PB = 128;  // sub-panel width == diagonal block edge == GEMM tile edge
+constexpr int MP = 8;    // micro-panel width of the in-LDS factorisation
 
 template <typename T>
 struct PanelCfg;
@@ -33,18 +34,35 @@ template <>
 struct PanelCfg<float> {
   static constexpr int XR = 128;       // appended rows per workgroup
   static constexpr int THREADS = 256;  // one thread per LDS row
+  static constexpr int LD = PB + 4;    // row stride (elements): 16-byte aligned rows, b128 reads conflict-free
 };
 template <>
 struct PanelCfg<double> {
-  static constexpr int XR = 16;        // 128x129 f64 diagonal block already takes 132 KB of LDS
+  static constexpr int XR = 16;        // the 128 x 130 f64 diagonal block already takes 133 KB of LDS
   static constexpr int THREADS = 192;
+  static constexpr int LD = PB + 2;
 };
+template <typename T>
+constexpr size_t panel_lds_bytes() {
+  return sizeof(T) * ((size_t)(PB + PanelCfg<T>::XR) * PanelCfg<T>::LD + MP * MP);
+}
 
 __device__ __forceinline__ float rsqrt_t(float x) { return __builtin_amdgcn_rsqf(x); }
 __device__ __forceinline__ double rsqrt_t(double x) { return 1.0 / sqrt(x); }
 
-// a: matrix base, j0: first column of the sub-panel, rows [j0, j0+128) are the diagonal block,
-// row blocks of XR rows follow from `rbeg` (== j0 + 128) up to n_total.
+// Fused POTRF + TRSM of one 128-column sub-panel, entirely in LDS / registers.
+//   a: matrix base, j0: first column of the sub-panel, rows [j0, j0+128) are the diagonal block,
+//   row blocks of XR rows follow from `rbeg` up to n_total; one workgroup per row block, and every
+//   workgroup re-factors the diagonal block (redundant, but it removes the potrf -> trsm launch
+//   dependency and needs no explicit inverse).
+// Algorithm: left-looking over micro-panels of MP = 8 columns, one thread per row.
+//   1. each thread pulls its 8 entries into registers and subtracts the contribution of all
+//      finished columns (dot products with the 8 pivot rows: 16-byte LDS reads, pivot rows broadcast);
+//   2. the 8 pivot rows publish their updated 8x8 diagonal micro-block; barrier;
+//   3. every thread factors that 8x8 block redundantly in registers and runs the 8-step
+//      triangular solve on its own 8 values (for a pivot row this reproduces its row of L,
+//      diagonal included: d * rsqrt(d) = sqrt(d)); writes them back; barrier.
+// 2 barriers per micro-panel (32 per sub-panel) instead of 2 per column.
 // prefactored != 0: the diagonal block already holds L (solve only; used by smn_trsm).
 template <typename T>
 __global__ void __launch_bounds__(PanelCfg<T>::THREADS) panel_kernel(T* __restrict__ a, int64_t lda, int64_t j0,
@@ -52,8 +70,11 @@ __global__ void __launch_bounds__(PanelCfg<T>::THREADS) panel_kernel(T* __restri
                                                                      double* __restrict__ logdet,
                                                                      int* __restrict__ info) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int XR = PanelCfg<T>::XR, NT = PanelCfg<T>::THREADS, LD = PB + 1;
-  T* S = reinterpret_cast<T*>(smem);  // [PB + XR][LD]
+  constexpr int XR = PanelCfg<T>::XR, NT = PanelCfg<T>::THREADS, LD = PanelCfg<T>::LD;
+  constexpr int VEC = 16 / sizeof(T);
+  using vec_t = typename Mfma<T>::vec_t;
+  T* S = reinterpret_cast<T*>(smem);        // [PB + XR][LD]
+  T* blk = S + (PB + XR) * LD;              // [MP][MP] staging of the diagonal micro-block
   const int tid = threadIdx.x;
   const int64_t rb = rbeg + (int64_t)blockIdx.x * XR;  // first appended row of this workgroup
   const int nx = (int)max((int64_t)0, min((int64_t)XR, n_total - rb));
@@ -68,50 +89,79 @@ __global__ void __launch_bounds__(PanelCfg<T>::THREADS) panel_kernel(T* __restri
   __syncthreads();
 
   const int row = tid;
-  const bool active = row < PB + nx;
-  const bool is_diag_row = row < PB;
+  const bool active = row < PB + nx && !(prefactored && row < PB);
   int bad = INT_MAX;
-  for (int j = 0; j < PB; ++j) {
-    const T d = S[j * LD + j];
-    T rinv;
-    if (prefactored) {
-      rinv = T(1) / d;
-    } else {
-      if (!(d > T(0)) && bad == INT_MAX) bad = j;
-      rinv = rsqrt_t(d);
-    }
-    T l = T(0);
-    const bool mine = active && row > j && !(prefactored && is_diag_row);
-    if (mine) {
-      l = S[row * LD + j] * rinv;
-      S[row * LD + j] = l;
+  double lgsum = 0.0;
+  for (int c0 = 0; c0 < PB; c0 += MP) {
+    const bool work = active && row >= c0;
+    T v[MP];
+    if (work) {
+#pragma unroll
+      for (int q = 0; q < MP; q += VEC) {
+        const vec_t t = *reinterpret_cast<const vec_t*>(&S[row * LD + c0 + q]);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) v[q + e] = t[e];
+      }
+      for (int k = 0; k < c0; k += VEC) {
+        const vec_t av = *reinterpret_cast<const vec_t*>(&S[row * LD + k]);
+#pragma unroll
+        for (int q = 0; q < MP; ++q) {
+          const vec_t bv = *reinterpret_cast<const vec_t*>(&S[(c0 + q) * LD + k]);
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) v[q] = fma(-av[e], bv[e], v[q]);
+        }
+      }
+      if (!prefactored && row < c0 + MP) {
+#pragma unroll
+        for (int q = 0; q < MP; ++q) blk[(row - c0) * MP + q] = v[q];
+      }
     }
     __syncthreads();
-    if (mine) {
-      const int cmax = is_diag_row ? row : PB - 1;
-      for (int c = j + 1; c <= cmax; ++c) S[row * LD + c] = fma(-l, S[c * LD + j], S[row * LD + c]);
+    if (work) {
+      T lm[MP][MP], rinv[MP];
+#pragma unroll
+      for (int i = 0; i < MP; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) lm[i][j] = prefactored ? S[(c0 + i) * LD + c0 + j] : blk[i * MP + j];
+      if (prefactored) {
+#pragma unroll
+        for (int j = 0; j < MP; ++j) rinv[j] = T(1) / lm[j][j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < MP; ++j) {
+          const T d = lm[j][j];
+          if (!(d > T(0)) && bad == INT_MAX) bad = c0 + j;
+          lgsum += log((double)d);
+          rinv[j] = rsqrt_t(d);
+#pragma unroll
+          for (int i = j + 1; i < MP; ++i) lm[i][j] *= rinv[j];
+#pragma unroll
+          for (int i = j + 1; i < MP; ++i)
+#pragma unroll
+            for (int jj = j + 1; jj <= i; ++jj) lm[i][jj] = fma(-lm[i][j], lm[jj][j], lm[i][jj]);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < MP; ++j) {
+        T x = v[j];
+#pragma unroll
+        for (int jj = 0; jj < j; ++jj) x = fma(-v[jj], lm[j][jj], x);
+        v[j] = x * rinv[j];
+      }
+#pragma unroll
+      for (int q = 0; q < MP; q += VEC) {
+        vec_t t;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) t[e] = v[q + e];
+        *reinterpret_cast<vec_t*>(&S[row * LD + c0 + q]) = t;
+      }
     }
     __syncthreads();
   }
 
   if (blockIdx.x == 0 && !prefactored) {
-    // diagonal entries still hold the pivots d_j = L_jj^2
-    double lg = 0.0;
-    if (tid < PB) {
-      const T d = S[tid * LD + tid];
-      lg = log((double)d);
-    }
-    __syncthreads();
-    if (tid < PB) S[tid * LD + tid] = sqrt(S[tid * LD + tid]);
-    // block reduce lg over the first PB threads (NT >= PB, multiple of 64)
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) lg += __shfl_xor(lg, o);
-    __shared__ double red[4];
-    if ((tid & 63) == 0 && tid < 256) red[tid >> 6] = lg;
-    __syncthreads();
-    if (tid == 0) {
-      double s = red[0] + red[1];  // PB = 128 -> waves 0 and 1 hold the pivots
-      atomicAdd(logdet, s);
+    if (tid == PB - 1) {  // the last diagonal row took part in every micro-panel: it saw all pivots
+      atomicAdd(logdet, lgsum);
       if (bad != INT_MAX) atomicMin(info, (int)(j0 + bad + 1));
     }
     for (int idx = tid; idx < PB * PB; idx += NT) {
@@ -149,10 +199,10 @@ __global__ void __launch_bounds__(256, sizeof(T) == 8 ? 1 : 2) update_kernel(Upd
   }
   const int64_t row0 = u.r0 + (int64_t)tr * kTile, col0 = u.c0 + (int64_t)tc * kTile;
   Tile t;
-  t.zero();
-  t.mainloop(u.a + row0 * u.lda + u.k0, u.lda, u.a + col0 * u.lda + u.k0, u.lda, u.K, smem);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wr = wave >> 1, wc = wave & 1;
+  // acc starts at -C so the C read is in flight together with the first operand loads and the
+  // epilogue is a pure store: acc = -C + A B^T, C_new = -acc.
 #pragma unroll
   for (int m = 0; m < Tile::MT; ++m)
 #pragma unroll
@@ -161,8 +211,18 @@ __global__ void __launch_bounds__(256, sizeof(T) == 8 ? 1 : 2) update_kernel(Upd
       for (int i = 0; i < M::ACC; ++i) {
         const int64_t gr = row0 + wr * Tile::WM + m * M::TM + M::acc_row(lane, i);
         const int64_t gc = col0 + wc * Tile::WN + n * M::TN + M::acc_col(lane);
-        T* p = u.a + gr * u.lda + gc;
-        *p = *p - t.acc[m][n][i];
+        t.acc[m][n][i] = -u.a[gr * u.lda + gc];
+      }
+  t.mainloop(u.a + row0 * u.lda + u.k0, u.lda, u.a + col0 * u.lda + u.k0, u.lda, u.K, smem);
+#pragma unroll
+  for (int m = 0; m < Tile::MT; ++m)
+#pragma unroll
+    for (int n = 0; n < Tile::NT; ++n)
+#pragma unroll
+      for (int i = 0; i < M::ACC; ++i) {
+        const int64_t gr = row0 + wr * Tile::WM + m * M::TM + M::acc_row(lane, i);
+        const int64_t gc = col0 + wc * Tile::WN + n * M::TN + M::acc_col(lane);
+        u.a[gr * u.lda + gc] = -t.acc[m][n][i];
       }
 }
 
@@ -222,7 +282,7 @@ int launch_panel(smn_ctx* ctx, hipStream_t st, T* a, int64_t lda, int64_t j0, in
   const int64_t rbeg = j0 + PB;
   const int64_t below = n_total - rbeg;
   const unsigned grid = below > 0 ? (unsigned)((below + XR - 1) / XR) : 1u;
-  const size_t lds = sizeof(T) * (size_t)(PB + XR) * (PB + 1);
+  const size_t lds = panel_lds_bytes<T>();
   auto kern = panel_kernel<T>;
   {
     ProfScope ps(ctx, PROF_PANEL, st);
@@ -239,7 +299,7 @@ int set_lds_attrs(smn_ctx* ctx) {
   if (done) return SMN_OK;
   SMN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(panel_kernel<T>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)(sizeof(T) * (PB + PanelCfg<T>::XR) * (PB + 1))));
+                                   (int)panel_lds_bytes<T>()));
   SMN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(update_kernel<T, 0>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)TileNT<T, kTile, kTile>::LDS_BYTES));
@@ -313,13 +373,13 @@ int solve_rows_padded(smn_ctx* ctx, int dtype, void* a, int64_t n_total, int64_t
       constexpr int XR = PanelCfg<double>::XR;
       const unsigned grid = (unsigned)((n_total - n_factor + XR - 1) / XR);
       hipLaunchKernelGGL(panel_kernel<double>, dim3(grid), dim3(PanelCfg<double>::THREADS),
-                         sizeof(double) * (size_t)(PB + XR) * (PB + 1), st, static_cast<double*>(a), lda, js, n_factor,
+                         panel_lds_bytes<double>(), st, static_cast<double*>(a), lda, js, n_factor,
                          n_total, 1, ctx->d_scal, ctx->d_info);
     } else {
       constexpr int XR = PanelCfg<float>::XR;
       const unsigned grid = (unsigned)((n_total - n_factor + XR - 1) / XR);
       hipLaunchKernelGGL(panel_kernel<float>, dim3(grid), dim3(PanelCfg<float>::THREADS),
-                         sizeof(float) * (size_t)(PB + XR) * (PB + 1), st, static_cast<float*>(a), lda, js, n_factor,
+                         panel_lds_bytes<float>(), st, static_cast<float*>(a), lda, js, n_factor,
                          n_total, 1, ctx->d_scal, ctx->d_info);
     }
     SMN_CHECK_LAUNCH(ctx);

@@ -80,7 +80,7 @@ class SPR(Module):
                              C.byref(info))
                     cov_data = float("nan") if info.value else quad.value / scale
                 else:
-                    cov_data = self.kernel.K(kernel_fn, self.x_data)
+                    cov_data = self.kernel.K(kernel_fn, self._f64_data()[0])   # fp64 for the same reason
             aux_dict = dict(cov_data=cov_data, y_data=self.y_host)
             aux = tuple(aux_dict[k] for k in require)
         else:
