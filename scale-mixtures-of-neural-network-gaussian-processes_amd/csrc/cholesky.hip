@@ -44,7 +44,7 @@ struct PanelCfg<double> {
 };
 template <typename T>
 constexpr size_t panel_lds_bytes() {
-  return sizeof(T) * ((size_t)(PB + PanelCfg<T>::XR) * PanelCfg<T>::LD + MP * MP);
+  return sizeof(T) * ((size_t)(PB + PanelCfg<T>::XR) * PanelCfg<T>::LD + MP * MP + PB);
 }
 
 __device__ __forceinline__ float rsqrt_t(float x) { return __builtin_amdgcn_rsqf(x); }
@@ -68,30 +68,41 @@ template <typename T>
 __global__ void __launch_bounds__(PanelCfg<T>::THREADS) panel_kernel(T* __restrict__ a, int64_t lda, int64_t j0,
                                                                      int64_t rbeg, int64_t n_total, int prefactored,
                                                                      double* __restrict__ logdet,
-                                                                     int* __restrict__ info) {
+                                                                     int* __restrict__ info, T* __restrict__ ldiag_out) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int XR = PanelCfg<T>::XR, NT = PanelCfg<T>::THREADS, LD = PanelCfg<T>::LD;
   constexpr int VEC = 16 / sizeof(T);
   using vec_t = typename Mfma<T>::vec_t;
   T* S = reinterpret_cast<T*>(smem);        // [PB + XR][LD]
   T* blk = S + (PB + XR) * LD;              // [MP][MP] staging of the diagonal micro-block
+  T* piv = blk + MP * MP;                   // [PB] pivots d_j = L_jj^2 (for logdet / info)
   const int tid = threadIdx.x;
   const int64_t rb = rbeg + (int64_t)blockIdx.x * XR;  // first appended row of this workgroup
   const int nx = (int)max((int64_t)0, min((int64_t)XR, n_total - rb));
-  for (int idx = tid; idx < PB * PB; idx += NT) {
-    const int r = idx / PB, c = idx % PB;
-    S[r * LD + c] = a[(j0 + r) * lda + j0 + c];
-  }
-  for (int idx = tid; idx < nx * PB; idx += NT) {
-    const int r = idx / PB, c = idx % PB;
-    S[(PB + r) * LD + c] = a[(rb + r) * lda + j0 + c];
-  }
+  // global -> LDS in 16-byte pieces, 8 loads in flight per thread (rows are 16-byte aligned on both sides)
+  constexpr int RV = PB / VEC;  // vectors per row
+  auto stage_in = [&](int lrow0, int64_t grow0, int nrows) {
+    const int nvec = nrows * RV;
+    for (int base = 0; base < nvec; base += NT * 8) {
+      vec_t tmp[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int idx = base + u * NT + tid;
+        if (idx < nvec) tmp[u] = *reinterpret_cast<const vec_t*>(&a[(grow0 + idx / RV) * lda + j0 + (idx % RV) * VEC]);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int idx = base + u * NT + tid;
+        if (idx < nvec) *reinterpret_cast<vec_t*>(&S[(lrow0 + idx / RV) * LD + (idx % RV) * VEC]) = tmp[u];
+      }
+    }
+  };
+  stage_in(0, j0, PB);
+  stage_in(PB, rb, nx);
   __syncthreads();
 
   const int row = tid;
   const bool active = row < PB + nx && !(prefactored && row < PB);
-  int bad = INT_MAX;
-  double lgsum = 0.0;
   for (int c0 = 0; c0 < PB; c0 += MP) {
     const bool work = active && row >= c0;
     T v[MP];
@@ -130,8 +141,7 @@ __global__ void __launch_bounds__(PanelCfg<T>::THREADS) panel_kernel(T* __restri
 #pragma unroll
         for (int j = 0; j < MP; ++j) {
           const T d = lm[j][j];
-          if (!(d > T(0)) && bad == INT_MAX) bad = c0 + j;
-          lgsum += log((double)d);
+          if (row == PB - 1) piv[c0 + j] = d;   // the last diagonal row takes part in every micro-panel
           rinv[j] = rsqrt_t(d);
 #pragma unroll
           for (int i = j + 1; i < MP; ++i) lm[i][j] *= rinv[j];
@@ -160,18 +170,41 @@ __global__ void __launch_bounds__(PanelCfg<T>::THREADS) panel_kernel(T* __restri
   }
 
   if (blockIdx.x == 0 && !prefactored) {
-    if (tid == PB - 1) {  // the last diagonal row took part in every micro-panel: it saw all pivots
-      atomicAdd(logdet, lgsum);
-      if (bad != INT_MAX) atomicMin(info, (int)(j0 + bad + 1));
+    // logdet += sum_j log d_j, info = first non-positive pivot (one log per thread, not per pivot per thread)
+    if (tid < 64) {   // one wave, two pivots per lane: a single deterministic atomic per sub-panel
+      const T d0 = piv[tid], d1 = piv[tid + 64];
+      double lg = log((double)d0) + log((double)d1);
+      int bad = !(d0 > T(0)) ? tid : (!(d1 > T(0)) ? tid + 64 : INT_MAX);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        lg += __shfl_xor(lg, o);
+        bad = min(bad, __shfl_xor(bad, o));
+      }
+      if (tid == 0) {
+        atomicAdd(logdet, lg);
+        if (bad != INT_MAX) atomicMin(info, (int)(j0 + bad + 1));
+      }
     }
-    for (int idx = tid; idx < PB * PB; idx += NT) {
-      const int r = idx / PB, c = idx % PB;
-      if (c <= r) a[(j0 + r) * lda + j0 + c] = S[r * LD + c];
+    // L_kk goes to a side buffer, NOT in place: the other workgroups of this launch still read the
+    // un-factored A_kk, and they may start after this one has finished (grid larger than the chip, or
+    // CUs shared with the trailing update on the other stream).  copy_diag_kernel moves it home.
+    for (int idx = tid; idx < PB * RV; idx += NT) {
+      const int r = idx / RV, c = (idx % RV) * VEC;
+      *reinterpret_cast<vec_t*>(&ldiag_out[r * PB + c]) = *reinterpret_cast<const vec_t*>(&S[r * LD + c]);
     }
   }
-  for (int idx = tid; idx < nx * PB; idx += NT) {
+  for (int idx = tid; idx < nx * RV; idx += NT) {
+    const int r = idx / RV, c = (idx % RV) * VEC;
+    *reinterpret_cast<vec_t*>(&a[(rb + r) * lda + j0 + c]) = *reinterpret_cast<const vec_t*>(&S[(PB + r) * LD + c]);
+  }
+}
+
+// Lower triangle of the factored diagonal block: side buffer -> matrix (stream-ordered after panel_kernel).
+template <typename T>
+__global__ void copy_diag_kernel(T* __restrict__ a, int64_t lda, int64_t j0, const T* __restrict__ ldiag) {
+  for (int idx = threadIdx.x; idx < PB * PB; idx += blockDim.x) {
     const int r = idx / PB, c = idx % PB;
-    a[(rb + r) * lda + j0 + c] = S[(PB + r) * LD + c];
+    if (c <= r) a[(j0 + r) * lda + j0 + c] = ldiag[idx];
   }
 }
 
@@ -257,14 +290,15 @@ __global__ void init_scalars_kernel(double* logdet, int* info) {
 
 template <typename T>
 int launch_update(smn_ctx* ctx, hipStream_t st, T* a, int64_t lda, int64_t r0, int64_t c0, int64_t k0, int K,
-                  int64_t tiles_m, int64_t tiles_n, int lower) {
+                  int64_t tiles_m, int64_t tiles_n, int lower, int tag = -1) {
   if (tiles_m <= 0 || tiles_n <= 0 || K <= 0) return SMN_OK;
+  if (tag < 0) tag = lower;   // 0: strip update, 1: trailing update (separate symbols / profile categories)
   UpdArgs<T> u{a, lda, r0, c0, k0, K, (int)tiles_n, lower};
   const int64_t nt = lower ? tiles_m * (tiles_m + 1) / 2 : tiles_m * tiles_n;
   const size_t lds = TileNT<T, kTile, kTile>::LDS_BYTES;
   {
-    ProfScope ps(ctx, lower ? PROF_TRAIL : PROF_STRIP, st);
-    if (lower) {
+    ProfScope ps(ctx, tag ? PROF_TRAIL : PROF_STRIP, st);
+    if (tag) {
       auto kern = update_kernel<T, 1>;
       hipLaunchKernelGGL(kern, dim3((unsigned)nt), dim3(256), lds, st, u);
     } else {
@@ -286,8 +320,10 @@ int launch_panel(smn_ctx* ctx, hipStream_t st, T* a, int64_t lda, int64_t j0, in
   auto kern = panel_kernel<T>;
   {
     ProfScope ps(ctx, PROF_PANEL, st);
+    T* ldiag = reinterpret_cast<T*>(ctx->d_diag);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(PanelCfg<T>::THREADS), lds, st, a, lda, j0, rbeg, n_total, prefactored,
-                       ctx->d_scal, ctx->d_info);
+                       ctx->d_scal, ctx->d_info, ldiag);
+    if (!prefactored) hipLaunchKernelGGL(copy_diag_kernel<T>, dim3(1), dim3(1024), 0, st, a, lda, j0, ldiag);
   }
   SMN_CHECK_LAUNCH(ctx);
   return SMN_OK;
@@ -323,17 +359,43 @@ int cholesky_t(smn_ctx* ctx, T* a, int64_t n_total, int64_t n_factor, int64_t ld
                        n_shift, jitter_abs, ridge_rel, ctx->d_scal + 1);
   }
   SMN_CHECK_LAUNCH(ctx);
+  // Optional look-ahead (ctx->lookahead): the panel chain of outer panel J+1 runs on stream2 beside the
+  // bulk of trailing update J; update J is then split into T0 (the two tile columns panel J+1 lives in)
+  // and T_rest, and stream2 waits for T0 only.  Off by default: with 135 KB of LDS a panel workgroup
+  // cannot share a CU with the two resident update workgroups, so today the chain just queues.
   constexpr int64_t W = 2 * PB;
+  const bool la = ctx->lookahead;
+  hipStream_t s2 = la ? ctx->stream2 : st;
+  if (la) {
+    SMN_HIP(ctx, hipEventRecord(ctx->ev_a, st));
+    SMN_HIP(ctx, hipStreamWaitEvent(s2, ctx->ev_a, 0));
+  }
   for (int64_t j0 = 0; j0 < n_factor; j0 += W) {
     const int64_t w = (n_factor - j0 < W) ? n_factor - j0 : W;
     for (int64_t js = j0; js < j0 + w; js += PB) {
       if (js > j0)  // bring the next sub-panel's column strip up to date: K = js - j0
-        SMN_TRY(launch_update<T>(ctx, st, a, lda, js, js, j0, (int)(js - j0), (n_total - js) / kTile, 1, 0));
-      SMN_TRY(launch_panel<T>(ctx, st, a, lda, js, n_total, 0));
+        SMN_TRY(launch_update<T>(ctx, s2, a, lda, js, js, j0, (int)(js - j0), (n_total - js) / kTile, 1, 0));
+      SMN_TRY(launch_panel<T>(ctx, s2, a, lda, js, n_total, 0));
+    }
+    if (la) {
+      SMN_HIP(ctx, hipEventRecord(ctx->ev_b, s2));
+      SMN_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_b, 0));
     }
     const int64_t j1 = j0 + w;
-    if (j1 < n_total)
-      SMN_TRY(launch_update<T>(ctx, st, a, lda, j1, j1, j0, (int)w, (n_total - j1) / kTile, (n_total - j1) / kTile, 1));
+    if (j1 >= n_total) break;
+    const int64_t tm = (n_total - j1) / kTile;
+    if (la && j1 < n_factor && tm > 2) {
+      SMN_TRY(launch_update<T>(ctx, st, a, lda, j1, j1, j0, (int)w, tm, 2, 0, 1));   // T0
+      SMN_HIP(ctx, hipEventRecord(ctx->ev_a, st));
+      SMN_HIP(ctx, hipStreamWaitEvent(s2, ctx->ev_a, 0));
+      SMN_TRY(launch_update<T>(ctx, st, a, lda, j1 + W, j1 + W, j0, (int)w, tm - 2, tm - 2, 1));
+    } else {
+      SMN_TRY(launch_update<T>(ctx, st, a, lda, j1, j1, j0, (int)w, tm, tm, 1));
+      if (la) {
+        SMN_HIP(ctx, hipEventRecord(ctx->ev_a, st));
+        SMN_HIP(ctx, hipStreamWaitEvent(s2, ctx->ev_a, 0));
+      }
+    }
   }
   return SMN_OK;
 }
@@ -374,13 +436,13 @@ int solve_rows_padded(smn_ctx* ctx, int dtype, void* a, int64_t n_total, int64_t
       const unsigned grid = (unsigned)((n_total - n_factor + XR - 1) / XR);
       hipLaunchKernelGGL(panel_kernel<double>, dim3(grid), dim3(PanelCfg<double>::THREADS),
                          panel_lds_bytes<double>(), st, static_cast<double*>(a), lda, js, n_factor,
-                         n_total, 1, ctx->d_scal, ctx->d_info);
+                         n_total, 1, ctx->d_scal, ctx->d_info, static_cast<double*>(nullptr));
     } else {
       constexpr int XR = PanelCfg<float>::XR;
       const unsigned grid = (unsigned)((n_total - n_factor + XR - 1) / XR);
       hipLaunchKernelGGL(panel_kernel<float>, dim3(grid), dim3(PanelCfg<float>::THREADS),
                          panel_lds_bytes<float>(), st, static_cast<float*>(a), lda, js, n_factor,
-                         n_total, 1, ctx->d_scal, ctx->d_info);
+                         n_total, 1, ctx->d_scal, ctx->d_info, static_cast<float*>(nullptr));
     }
     SMN_CHECK_LAUNCH(ctx);
   }

@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -24,6 +25,7 @@ struct smn_ctx {
   // small device scalar block: [0..15] doubles scratch, ints after
   double* d_scal = nullptr;   // 64 doubles
   int* d_info = nullptr;      // 16 ints
+  void* d_diag = nullptr;     // 128 x 128 doubles: side buffer for the factored diagonal block
   void* comm = nullptr;       // ncclComm_t when smn_comm_init was called
   int nranks = 1, rank = 0;
   // per-kernel timing (smn_profile_*): hipEvent pairs around launches, resolved on read
@@ -31,6 +33,7 @@ struct smn_ctx {
   std::vector<hipEvent_t> prof_ev;   // pool, used pairwise
   std::vector<int> prof_cat;         // category of pair i
   size_t prof_used = 0;              // events handed out
+  bool lookahead = false;            // Cholesky look-ahead on stream2 (env SMN_LOOKAHEAD=1)
 };
 
 enum { PROF_PREP = 0, PROF_BUILD = 1, PROF_RECURSION = 2, PROF_PANEL = 3, PROF_STRIP = 4, PROF_TRAIL = 5,

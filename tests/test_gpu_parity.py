@@ -151,6 +151,29 @@ def test_cholesky_and_schur(L, ctx, dtype, n, m):
         assert relerr(np.tril(got[n:, n:]), np.tril(s)) < tol
 
 
+@pytest.mark.parametrize("dtype,n,m", [(np.float64, 6144, 128), (np.float32, 8192, 0)])
+def test_cholesky_more_workgroups_than_cus_and_lookahead(L, ctx, dtype, n, m):
+    """Sizes where a panel launch has more workgroups than the chip has CUs (f64: 16 rows per workgroup)
+    and where the look-ahead stream runs beside the trailing update: late workgroups must still see the
+    un-factored diagonal block."""
+    rng = np.random.default_rng(99)
+    g = rng.standard_normal((n + m, 64))
+    a = g @ g.T / 64 + np.diag(rng.uniform(1.0, 2.0, n + m))
+    ad = ctx.to_device(a.astype(dtype))
+    info, logdet = C.c_int(), C.c_double()
+    ctx.call("smn_cholesky", L.dtype_code(dtype), ad.ptr, n + m, n, n + m, 0, 0.0, 0.0, C.byref(info), C.byref(logdet))
+    l = np.linalg.cholesky(a[:n, :n])
+    tol = 1e-9 if dtype == np.float64 else 2e-3
+    assert info.value == 0
+    assert abs(logdet.value - 2 * np.log(np.diag(l)).sum()) < tol * abs(logdet.value)
+    got = ad.numpy().astype(np.float64)
+    assert relerr(np.tril(got[:n, :n]), l) < tol
+    if m:
+        w = sla.solve_triangular(l, a[:n, n:], lower=True).T
+        assert relerr(got[n:, :n], w) < tol
+        assert relerr(np.tril(got[n:, n:]), np.tril(a[n:, n:] - w @ w.T)) < tol
+
+
 def test_cholesky_shift_and_not_pd(L, ctx):
     rng = np.random.default_rng(11)
     n = 200
