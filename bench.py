@@ -62,7 +62,8 @@ def cholesky_launch_model(n_total, n_factor):
         j1 = j0 + w
         if j1 < n_total:
             t = (n_total - j1) // TILE
-            if j1 < n_factor and t > 2:      # look-ahead split: T0 = 2 full tile columns, T_rest = lower tiles
+            if os.environ.get("SMN_LOOKAHEAD", "0") == "1" and j1 < n_factor and t > 2:
+                # look-ahead split: T0 = 2 full tile columns, T_rest = lower tiles
                 trail += (2 * t + (t - 2) * (t - 1) // 2) * TILE * TILE * 2.0 * w
                 n_trail += 2
             else:

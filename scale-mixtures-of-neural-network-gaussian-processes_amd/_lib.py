@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsmnngp.so")
+LIB_PATH = os.environ.get("SMNNGP_LIB") or os.path.join(_HERE, "libsmnngp.so")   # override: A/B builds only
 
 OK, EINVAL, EHIP, ENOMEM, ENOTSUP, ECOMM = 0, -1, -2, -3, -4, -5
 F32, F64 = 0, 1

@@ -1,4 +1,8 @@
-"""Builds libsmnngp.so (gfx950) in-tree with hipcc.  No JIT cache: the .so travels with the repo snapshot."""
+"""Builds libsmnngp.so (gfx950) in-tree with hipcc.  No JIT cache: the .so travels with the repo snapshot.
+
+    python build.py                    -> libsmnngp.so
+    python build.py --variant s1 -DSMN_STAGES=1   -> libsmnngp_s1.so (A/B builds; select with SMNNGP_LIB=...)
+"""
 import os
 import subprocess
 import sys
@@ -6,8 +10,6 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OBJ = os.path.join(HERE, "build")
-LIB = os.path.join(HERE, "libsmnngp.so")
 SOURCES = ["api.hip", "kernel_build.hip", "cholesky.hip", "heads.hip", "comm.hip", "cnn.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
          "-fno-gpu-rdc", "-ffp-contract=fast"]
@@ -20,21 +22,24 @@ def _newer(src_list, target):
     return any(os.path.getmtime(s) > t for s in src_list)
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, variant="", defines=()):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    os.makedirs(OBJ, exist_ok=True)
+    suffix = "_" + variant if variant else ""
+    objdir = os.path.join(HERE, "build" + suffix)
+    lib = os.path.join(HERE, "libsmnngp%s.so" % suffix)
+    os.makedirs(objdir, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
     headers.append(os.path.join(HERE, "..", "include", "smnngp.h"))
     jobs = []
     for s in SOURCES:
         src = os.path.join(CSRC, s)
-        obj = os.path.join(OBJ, s.replace(".hip", ".o"))
+        obj = os.path.join(objdir, s.replace(".hip", ".o"))
         if force or _newer([src] + headers, obj):
             jobs.append((src, obj))
 
     def cc(job):
         src, obj = job
-        cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+        cmd = [hipcc] + FLAGS + list(defines) + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
@@ -46,14 +51,21 @@ def build(force=False, verbose=False):
 
     with ThreadPoolExecutor(max_workers=min(6, max(1, len(jobs)))) as ex:
         list(ex.map(cc, jobs))
-    objs = [os.path.join(OBJ, s.replace(".hip", ".o")) for s in SOURCES]
-    if force or jobs or _newer(objs, LIB):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
+    objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in SOURCES]
+    if force or jobs or _newer(objs, lib):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs + ["-ldl"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    argv = sys.argv[1:]
+    variant = ""
+    if "--variant" in argv:
+        i = argv.index("--variant")
+        variant = argv[i + 1]
+        del argv[i:i + 2]
+    defs = [a for a in argv if a.startswith("-D")]
+    print(build(force="--force" in argv, verbose=True, variant=variant, defines=defs))

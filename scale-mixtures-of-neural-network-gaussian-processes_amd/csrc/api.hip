@@ -162,14 +162,14 @@ extern "C" int smn_ctx_create(int device_id, smn_ctx** out) {
   smn_ctx* c = new smn_ctx();
   c->device = device_id;
   if (const char* e = getenv("SMN_LOOKAHEAD")) c->lookahead = e[0] == '1';
+  if (const char* e = getenv("SMN_XCD_MAP")) c->xcd_map = e[0] == '1';
   bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
             hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) == hipSuccess &&
             hipEventCreateWithFlags(&c->ev_a, hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&c->ev_b, hipEventDisableTiming) == hipSuccess &&
             hipEventCreate(&c->ev_t0) == hipSuccess && hipEventCreate(&c->ev_t1) == hipSuccess &&
             hipMalloc(reinterpret_cast<void**>(&c->d_scal), 64 * sizeof(double)) == hipSuccess &&
-            hipMalloc(reinterpret_cast<void**>(&c->d_info), 16 * sizeof(int)) == hipSuccess &&
-            hipMalloc(&c->d_diag, 128 * 128 * sizeof(double)) == hipSuccess;
+            hipMalloc(reinterpret_cast<void**>(&c->d_info), 16 * sizeof(int)) == hipSuccess;
   if (!ok) {
     smn_ctx_destroy(c);
     return SMN_EHIP;
@@ -188,7 +188,6 @@ extern "C" int smn_ctx_destroy(smn_ctx* c) {
   for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
   if (c->d_scal) (void)hipFree(c->d_scal);
   if (c->d_info) (void)hipFree(c->d_info);
-  if (c->d_diag) (void)hipFree(c->d_diag);
   if (c->ev_a) (void)hipEventDestroy(c->ev_a);
   if (c->ev_b) (void)hipEventDestroy(c->ev_b);
   if (c->ev_t0) (void)hipEventDestroy(c->ev_t0);

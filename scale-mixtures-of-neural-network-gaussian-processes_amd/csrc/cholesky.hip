@@ -103,7 +103,32 @@ __global__ void __launch_bounds__(PanelCfg<T>::THREADS) panel_kernel(T* __restri
 
   const int row = tid;
   const bool active = row < PB + nx && !(prefactored && row < PB);
+  using M = Mfma<T>;
+  constexpr int CB = 32;                               // column block brought up to date on the MFMA
+  constexpr int NW = NT / 64;                          // waves
+  constexpr int RT = (PB + XR) / M::TM, CT = CB / M::TN;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = M::frag_row(lane), fk = M::frag_chunk(lane, 0) * VEC;   // fragment row / k offset in an 8-k group
   for (int c0 = 0; c0 < PB; c0 += MP) {
+    const int cb = c0 & ~(CB - 1);                     // first column of the current 32-column block
+    if (c0 == cb && cb > 0) {
+      // S[rows >= rmin, cb:cb+32] -= S[rows, 0:cb] * S[cb:cb+32, 0:cb]^T   (MFMA, operands straight from S)
+      const int rmin = prefactored ? PB : cb;
+      for (int p = wave; p < RT * CT; p += NW) {
+        const int rt = (p / CT) * M::TM, ct = cb + (p % CT) * M::TN;
+        if (rt < rmin) continue;
+        typename M::acc_t acc;
+#pragma unroll
+        for (int i = 0; i < M::ACC; ++i) acc[i] = -S[(rt + M::acc_row(lane, i)) * LD + ct + M::acc_col(lane)];
+        const T* pa = &S[(rt + fr) * LD + fk];
+        const T* pb = &S[(ct + fr) * LD + fk];
+        for (int kb = 0; kb < cb; kb += 8)
+          M::mma(acc, *reinterpret_cast<const vec_t*>(pa + kb), *reinterpret_cast<const vec_t*>(pb + kb));
+#pragma unroll
+        for (int i = 0; i < M::ACC; ++i) S[(rt + M::acc_row(lane, i)) * LD + ct + M::acc_col(lane)] = -acc[i];
+      }
+      __syncthreads();
+    }
     const bool work = active && row >= c0;
     T v[MP];
     if (work) {
@@ -113,7 +138,7 @@ __global__ void __launch_bounds__(PanelCfg<T>::THREADS) panel_kernel(T* __restri
 #pragma unroll
         for (int e = 0; e < VEC; ++e) v[q + e] = t[e];
       }
-      for (int k = 0; k < c0; k += VEC) {
+      for (int k = cb; k < c0; k += VEC) {   // columns left of cb were folded in by the MFMA block update
         const vec_t av = *reinterpret_cast<const vec_t*>(&S[row * LD + k]);
 #pragma unroll
         for (int q = 0; q < MP; ++q) {
@@ -187,7 +212,7 @@ __global__ void __launch_bounds__(PanelCfg<T>::THREADS) panel_kernel(T* __restri
     }
     // L_kk goes to a side buffer, NOT in place: the other workgroups of this launch still read the
     // un-factored A_kk, and they may start after this one has finished (grid larger than the chip, or
-    // CUs shared with the trailing update on the other stream).  copy_diag_kernel moves it home.
+    // CUs shared with the trailing update on the other stream).  copy_diag_kernel moves it home at the end.
     for (int idx = tid; idx < PB * RV; idx += NT) {
       const int r = idx / RV, c = (idx % RV) * VEC;
       *reinterpret_cast<vec_t*>(&ldiag_out[r * PB + c]) = *reinterpret_cast<const vec_t*>(&S[r * LD + c]);
@@ -199,12 +224,15 @@ __global__ void __launch_bounds__(PanelCfg<T>::THREADS) panel_kernel(T* __restri
   }
 }
 
-// Lower triangle of the factored diagonal block: side buffer -> matrix (stream-ordered after panel_kernel).
+// Lower triangles of ALL factored diagonal blocks: side buffer -> matrix, once, after the last panel
+// (nothing inside the factorisation reads L_kk again; the LML / predictive heads never need it).
 template <typename T>
-__global__ void copy_diag_kernel(T* __restrict__ a, int64_t lda, int64_t j0, const T* __restrict__ ldiag) {
+__global__ void copy_diag_kernel(T* __restrict__ a, int64_t lda, const T* __restrict__ ldiag) {
+  const int64_t j0 = (int64_t)blockIdx.x * PB;
+  const T* src = ldiag + (int64_t)blockIdx.x * PB * PB;
   for (int idx = threadIdx.x; idx < PB * PB; idx += blockDim.x) {
     const int r = idx / PB, c = idx % PB;
-    if (c <= r) a[(j0 + r) * lda + j0 + c] = ldiag[idx];
+    if (c <= r) a[(j0 + r) * lda + j0 + c] = src[idx];
   }
 }
 
@@ -214,6 +242,7 @@ __global__ void copy_diag_kernel(T* __restrict__ a, int64_t lda, int64_t j0, con
 template <typename T>
 struct UpdArgs {
   T* a; int64_t lda; int64_t r0, c0, k0; int K; int tiles_n; int lower;
+  int use_map; TileMap map;   // XCD-aware patch order (gemm_nt.hpp) instead of the linear one
 };
 
 // TAG only separates the two uses into two symbols (0: strip update, 1: trailing update) so that
@@ -221,10 +250,12 @@ struct UpdArgs {
 template <typename T, int TAG>
 __global__ void __launch_bounds__(256, sizeof(T) == 8 ? 1 : 2) update_kernel(UpdArgs<T> u) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  using Tile = TileNT<T, kTile, kTile>;
+  using Tile = MainTile<T>;
   using M = typename Tile::M;
   int tr, tc;
-  if (u.lower) {
+  if (u.use_map) {
+    if (!u.map.decode(blockIdx.x, tr, tc)) return;   // padding slot of a patch (uniform per workgroup)
+  } else if (u.lower) {
     tri_decode(blockIdx.x, tr, tc);
   } else {
     tr = blockIdx.x / u.tiles_n;
@@ -293,9 +324,13 @@ int launch_update(smn_ctx* ctx, hipStream_t st, T* a, int64_t lda, int64_t r0, i
                   int64_t tiles_m, int64_t tiles_n, int lower, int tag = -1) {
   if (tiles_m <= 0 || tiles_n <= 0 || K <= 0) return SMN_OK;
   if (tag < 0) tag = lower;   // 0: strip update, 1: trailing update (separate symbols / profile categories)
-  UpdArgs<T> u{a, lda, r0, c0, k0, K, (int)tiles_n, lower};
-  const int64_t nt = lower ? tiles_m * (tiles_m + 1) / 2 : tiles_m * tiles_n;
-  const size_t lds = TileNT<T, kTile, kTile>::LDS_BYTES;
+  UpdArgs<T> u{a, lda, r0, c0, k0, K, (int)tiles_n, lower, 0, TileMap::make(tiles_m, tiles_n, lower)};
+  int64_t nt = lower ? tiles_m * (tiles_m + 1) / 2 : tiles_m * tiles_n;
+  if (ctx->xcd_map && nt >= 512) {   // small launches do not fill the XCDs anyway
+    u.use_map = 1;
+    nt = u.map.grid;
+  }
+  const size_t lds = MainTile<T>::LDS_BYTES;
   {
     ProfScope ps(ctx, tag ? PROF_TRAIL : PROF_STRIP, st);
     if (tag) {
@@ -320,10 +355,9 @@ int launch_panel(smn_ctx* ctx, hipStream_t st, T* a, int64_t lda, int64_t j0, in
   auto kern = panel_kernel<T>;
   {
     ProfScope ps(ctx, PROF_PANEL, st);
-    T* ldiag = reinterpret_cast<T*>(ctx->d_diag);
+    T* ldiag = reinterpret_cast<T*>(ctx->ws[3]) + (j0 / PB) * (int64_t)(PB * PB);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(PanelCfg<T>::THREADS), lds, st, a, lda, j0, rbeg, n_total, prefactored,
                        ctx->d_scal, ctx->d_info, ldiag);
-    if (!prefactored) hipLaunchKernelGGL(copy_diag_kernel<T>, dim3(1), dim3(1024), 0, st, a, lda, j0, ldiag);
   }
   SMN_CHECK_LAUNCH(ctx);
   return SMN_OK;
@@ -338,18 +372,20 @@ int set_lds_attrs(smn_ctx* ctx) {
                                    (int)panel_lds_bytes<T>()));
   SMN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(update_kernel<T, 0>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)TileNT<T, kTile, kTile>::LDS_BYTES));
+                                   (int)MainTile<T>::LDS_BYTES));
   SMN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(update_kernel<T, 1>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)TileNT<T, kTile, kTile>::LDS_BYTES));
+                                   (int)MainTile<T>::LDS_BYTES));
   done = true;
   return SMN_OK;
 }
 
 template <typename T>
 int cholesky_t(smn_ctx* ctx, T* a, int64_t n_total, int64_t n_factor, int64_t lda, int64_t n_shift, double jitter_abs,
-               double ridge_rel) {
+               double ridge_rel, bool keep_factor) {
   SMN_TRY(set_lds_attrs<T>(ctx));
+  void* side = nullptr;   // factored diagonal blocks, [n_factor/128][128*128]
+  SMN_TRY(smn_workspace(ctx, 3, sizeof(T) * (size_t)n_factor * PB, &side));
   hipStream_t st = ctx->stream;
   hipLaunchKernelGGL(init_scalars_kernel, dim3(1), dim3(1), 0, st, ctx->d_scal, ctx->d_info);
   if (n_shift > 0 && (jitter_abs != 0.0 || ridge_rel != 0.0)) {
@@ -397,21 +433,27 @@ int cholesky_t(smn_ctx* ctx, T* a, int64_t n_total, int64_t n_factor, int64_t ld
       }
     }
   }
+  if (keep_factor) {
+    hipLaunchKernelGGL(copy_diag_kernel<T>, dim3((unsigned)(n_factor / PB)), dim3(1024), 0, st, a, lda,
+                       static_cast<const T*>(side));
+    SMN_CHECK_LAUNCH(ctx);
+  }
   return SMN_OK;
 }
 
 }  // namespace
 
 int cholesky_padded(smn_ctx* ctx, int dtype, void* a, int64_t n_total, int64_t n_factor, int64_t lda, int64_t n_shift,
-                    double jitter_abs, double ridge_rel) {
+                    double jitter_abs, double ridge_rel, bool keep_factor) {
   if (n_total % kTile || n_factor % kTile || n_factor > n_total || n_factor <= 0)
     return smn_fail(ctx, SMN_EINVAL, "cholesky_padded: n_total=%lld n_factor=%lld must be multiples of %d",
                     (long long)n_total, (long long)n_factor, kTile);
   if (lda % (16 / (int)dtype_size(dtype)) || (reinterpret_cast<uintptr_t>(a) & 15))
     return smn_fail(ctx, SMN_EINVAL, "cholesky_padded: matrix must be 16-byte aligned");
   if (dtype == SMN_F64)
-    return cholesky_t<double>(ctx, static_cast<double*>(a), n_total, n_factor, lda, n_shift, jitter_abs, ridge_rel);
-  return cholesky_t<float>(ctx, static_cast<float*>(a), n_total, n_factor, lda, n_shift, jitter_abs, ridge_rel);
+    return cholesky_t<double>(ctx, static_cast<double*>(a), n_total, n_factor, lda, n_shift, jitter_abs, ridge_rel,
+                              keep_factor);
+  return cholesky_t<float>(ctx, static_cast<float*>(a), n_total, n_factor, lda, n_shift, jitter_abs, ridge_rel, keep_factor);
 }
 
 // Solve-only sweep: rows [n_factor, n_total) of `a` <- rows * L^-T with L = the (already factored)

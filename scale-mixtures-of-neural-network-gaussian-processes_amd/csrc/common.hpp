@@ -25,7 +25,6 @@ struct smn_ctx {
   // small device scalar block: [0..15] doubles scratch, ints after
   double* d_scal = nullptr;   // 64 doubles
   int* d_info = nullptr;      // 16 ints
-  void* d_diag = nullptr;     // 128 x 128 doubles: side buffer for the factored diagonal block
   void* comm = nullptr;       // ncclComm_t when smn_comm_init was called
   int nranks = 1, rank = 0;
   // per-kernel timing (smn_profile_*): hipEvent pairs around launches, resolved on read
@@ -34,6 +33,8 @@ struct smn_ctx {
   std::vector<int> prof_cat;         // category of pair i
   size_t prof_used = 0;              // events handed out
   bool lookahead = false;            // Cholesky look-ahead on stream2 (env SMN_LOOKAHEAD=1)
+  bool xcd_map = false;              // XCD-aware patch tile order (env SMN_XCD_MAP=1): measured 2-6 % SLOWER
+                                     // than the linear order on C4 (profiles/README.md), so off by default
 };
 
 enum { PROF_PREP = 0, PROF_BUILD = 1, PROF_RECURSION = 2, PROF_PANEL = 3, PROF_STRIP = 4, PROF_TRAIL = 5,

@@ -70,7 +70,7 @@ struct Mfma<double> {
   static __device__ __forceinline__ int acc_col(int lane) { return lane & 15; }
 };
 
-template <typename T, int BM_, int BN_>
+template <typename T, int BM_, int BN_, int STAGES_ = 2>
 struct TileNT {
   using M = Mfma<T>;
   using acc_t = typename M::acc_t;
@@ -82,7 +82,8 @@ struct TileNT {
   static constexpr int ROWB = 128;                            // LDS bytes per row per K-step
   static constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB;
   static constexpr int STAGE = A_BYTES + B_BYTES;
-  static constexpr int LDS_BYTES = 2 * STAGE;
+  static constexpr int STAGES = STAGES_;                      // 2: double-buffered LDS (1 barrier per K-step); 1: single buffer
+  static constexpr int LDS_BYTES = STAGES * STAGE;           //    (2 barriers per K-step, half the LDS -> twice the workgroups per CU)
   static constexpr int PA = BM / 32, PB = BN / 32;            // 16-byte loads per thread per K-step
   static_assert(BM % 32 == 0 && BN % 32 == 0 && WM % M::TM == 0 && WN % M::TN == 0, "tile shape");
   static_assert(WM % 16 == 0 && WN % 16 == 0, "swizzle assumes 16-row aligned wave blocks");
@@ -153,9 +154,10 @@ struct TileNT {
         for (int p = 0; p < PB; ++p)
           rb[p] = *reinterpret_cast<const vec_t*>(gb + (int64_t)(32 * p) * ldb + ko);
       }
-      compute(smem + (kt & 1) * STAGE, lane, wr, wc);
+      compute(smem + (STAGES == 2 ? (kt & 1) * STAGE : 0), lane, wr, wc);
       if (more) {
-        char* st = smem + ((kt + 1) & 1) * STAGE;
+        if (STAGES == 1) __syncthreads();   // every wave is done reading the only buffer
+        char* st = smem + (STAGES == 2 ? ((kt + 1) & 1) * STAGE : 0);
 #pragma unroll
         for (int p = 0; p < PA; ++p) *reinterpret_cast<vec_t*>(st + wpos + 32 * p * ROWB) = ra[p];
 #pragma unroll
@@ -182,10 +184,57 @@ struct TileNT {
 };
 
 // Lower-triangular tile enumeration: linear index t -> (tr, tc) with tc <= tr, row-major.
-__device__ __forceinline__ void tri_decode(int64_t t, int& tr, int& tc) {
+__host__ __device__ __forceinline__ void tri_decode(int64_t t, int& tr, int& tc) {
   int r = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
   while ((int64_t)(r + 1) * (r + 2) / 2 <= t) ++r;
   while ((int64_t)r * (r + 1) / 2 > t) --r;
   tr = r;
   tc = (int)(t - (int64_t)r * (r + 1) / 2);
 }
+
+// XCD-aware blockIdx -> tile map (cdna_hip_programming.md T1).  Workgroups are dealt round-robin over
+// the 8 XCDs, each with its own 4 MiB L2, so block b and block b+8 share an L2.  Tiles are enumerated
+// patch-major (patches of PS x PS tiles, row-major inside a patch) and every XCD gets one contiguous
+// range of that order: the ~64 workgroups resident on an XCD then work on one patch and share
+// 2*PS operand panels out of L2 instead of fetching 2 per tile from the Infinity Cache.
+// Placement only changes speed: any dispatch order computes the same tiles.
+struct TileMap {
+  int tm, tn;        // tile grid
+  int lower;         // 1: only tiles with tc <= tr (tm == tn)
+  int pm, pn;        // patch grid
+  int npatch;        // patches enumerated (lower: pm*(pm+1)/2)
+  int grid;          // launch size: npatch * PS*PS rounded up to a multiple of 8
+  static constexpr int PS = 8;
+  static TileMap make(int64_t tm_, int64_t tn_, int lower_) {
+    TileMap t;
+    t.tm = (int)tm_; t.tn = (int)tn_; t.lower = lower_;
+    t.pm = (t.tm + PS - 1) / PS; t.pn = (t.tn + PS - 1) / PS;
+    t.npatch = lower_ ? t.pm * (t.pm + 1) / 2 : t.pm * t.pn;
+    t.grid = (t.npatch * PS * PS + 7) / 8 * 8;
+    return t;
+  }
+  __device__ __forceinline__ bool decode(unsigned b, int& tr, int& tc) const {
+    const int chunk = grid >> 3;
+    const int l = (int)(b & 7) * chunk + (int)(b >> 3);
+    const int patch = l / (PS * PS), slot = l % (PS * PS);
+    if (patch >= npatch) return false;
+    int sr, sc;
+    if (lower) {
+      tri_decode(patch, sr, sc);
+    } else {
+      sr = patch / pn;
+      sc = patch % pn;
+    }
+    tr = sr * PS + slot / PS;
+    tc = sc * PS + slot % PS;
+    return tr < tm && tc < tn && (!lower || tc <= tr);
+  }
+};
+
+// The 128 x 128 tile every dense kernel of the path uses.  SMN_STAGES (build-time) selects LDS
+// double-buffering (2, default) or a single buffer (1).
+#ifndef SMN_STAGES
+#define SMN_STAGES 2
+#endif
+template <typename T>
+using MainTile = TileNT<T, 128, 128, SMN_STAGES>;

@@ -82,7 +82,7 @@ int aug_build(smn_ctx* ctx, const BuildSpec& spec, const Aug& g, const void* x, 
 int aug_finish(smn_ctx* ctx, int dtype, const Aug& g, const void* y, int64_t ldy, int64_t n_shift, double jitter_abs,
                double ridge_rel, void* mean, void* cov, int64_t ldcov, double* quad_h, double* logdet_h, int* info_h) {
   SMN_TRY(set_aug_rows(ctx, dtype, g.a, g.lda, g.n_pad + g.t, g.n_total, y, g.n, g.c, ldy));
-  SMN_TRY(cholesky_padded(ctx, dtype, g.a, g.n_total, g.n_pad, g.lda, n_shift, jitter_abs, ridge_rel));
+  SMN_TRY(cholesky_padded(ctx, dtype, g.a, g.n_total, g.n_pad, g.lda, n_shift, jitter_abs, ridge_rel, false));
   double* quad_dev = ctx->d_scal + 8;
   if (g.c > 48) return smn_fail(ctx, SMN_ENOTSUP, "more than 48 output columns");
   SMN_TRY(extract_posterior(ctx, dtype, g.a, g.lda, g.n_pad, g.t, g.c, mean, cov, ldcov, quad_dev));
@@ -112,7 +112,7 @@ extern "C" int smn_cholesky(smn_ctx* ctx, int dtype, void* a_d, int64_t n_total,
   const bool inplace = n_total % kTile == 0 && n_factor % kTile == 0 && lda % (16 / (int64_t)es) == 0 &&
                        (reinterpret_cast<uintptr_t>(a_d) & 15) == 0;
   if (inplace) {
-    SMN_TRY(cholesky_padded(ctx, dtype, a_d, n_total, n_factor, lda, n_shift, jitter_abs, ridge_rel));
+    SMN_TRY(cholesky_padded(ctx, dtype, a_d, n_total, n_factor, lda, n_shift, jitter_abs, ridge_rel, true));
   } else {
     const int64_t m = n_total - n_factor, nfp = round_up(n_factor, kTile), ntp = nfp + round_up(m, kTile);
     void* w = nullptr;
@@ -124,7 +124,7 @@ extern "C" int smn_cholesky(smn_ctx* ctx, int dtype, void* a_d, int64_t n_total,
     SMN_TRY(copy_matrix(ctx, dtype, wb + es * (size_t)(nfp * ntp), ntp, ab + es * (size_t)(n_factor * lda), lda, m, n_factor, 0));
     SMN_TRY(copy_matrix(ctx, dtype, wb + es * (size_t)(nfp * ntp + nfp), ntp, ab + es * (size_t)(n_factor * lda + n_factor), lda, m, m, 1));
     SMN_TRY(fill_identity_pad(ctx, dtype, w, ntp, nfp, n_factor));
-    SMN_TRY(cholesky_padded(ctx, dtype, w, ntp, nfp, ntp, n_shift, jitter_abs, ridge_rel));
+    SMN_TRY(cholesky_padded(ctx, dtype, w, ntp, nfp, ntp, n_shift, jitter_abs, ridge_rel, true));
     char* ao = static_cast<char*>(a_d);
     SMN_TRY(copy_matrix(ctx, dtype, ao, lda, wb, ntp, n_factor, n_factor, 1));
     SMN_TRY(copy_matrix(ctx, dtype, ao + es * (size_t)(n_factor * lda), lda, wb + es * (size_t)(nfp * ntp), ntp, m, n_factor, 0));

@@ -40,7 +40,7 @@ inline int64_t k_pad(int dtype, int64_t d) { return round_up(d, dtype == SMN_F64
 // Partial Cholesky on a padded matrix (n_total, n_factor multiples of 128).  Device-side results:
 // logdet (double) and info (int) are left in ctx->d_scal[0] / ctx->d_info[0]; no host sync.
 int cholesky_padded(smn_ctx* ctx, int dtype, void* a, int64_t n_total, int64_t n_factor, int64_t lda,
-                    int64_t n_shift, double jitter_abs, double ridge_rel);
+                    int64_t n_shift, double jitter_abs, double ridge_rel, bool keep_factor);
 int fetch_logdet_info(smn_ctx* ctx, double* logdet, int* info);
 
 // small helpers implemented in util.hip

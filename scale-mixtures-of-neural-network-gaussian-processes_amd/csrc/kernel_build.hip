@@ -90,15 +90,18 @@ struct BuildArgs {
   int64_t row_off, col_off; int exact_diag;
   int store_mode; int64_t out_rows, out_cols; int64_t nv0, aug0, nv1;
   T* out_k; T* out_t; int64_t ldo;
+  int use_map; TileMap map;   // XCD-aware patch order (gemm_nt.hpp)
 };
 
 template <typename T, int NET, int ACT, bool NTK>
 __global__ void __launch_bounds__(256, (NTK || sizeof(T) == 8) ? 1 : 2) build_kernel(BuildArgs<T> a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  using Tile = TileNT<T, kTile, kTile>;
+  using Tile = MainTile<T>;
   using M = typename Tile::M;
   int tr, tc;
-  if (a.symmetric) {
+  if (a.use_map) {
+    if (!a.map.decode(blockIdx.x, tr, tc)) return;
+  } else if (a.symmetric) {
     tri_decode(blockIdx.x, tr, tc);
   } else {
     tr = blockIdx.x / a.tiles_n;
@@ -310,6 +313,10 @@ int make_prog(smn_ctx* ctx, const BuildSpec& s, LayerProg* p) {
 template <typename T, int NET, int ACT, bool NTK>
 int launch_build_t(smn_ctx* ctx, const BuildArgs<T>& a, int64_t ntiles, size_t lds) {
   auto kern = build_kernel<T, NET, ACT, NTK>;
+  if (const char* e = getenv("SMN_DEBUG_LDS")) {   // occupancy experiments only: inflate the LDS request
+    const size_t want = (size_t)atol(e);
+    if (want > lds && want <= 160 * 1024) lds = want;
+  }
   SMN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   {
@@ -375,8 +382,14 @@ int run_build_t(smn_ctx* ctx, const BuildCall& c) {
   a.out_k = (c.get_mask & SMN_GET_NNGP) ? static_cast<T*>(c.out_k) : nullptr;
   a.out_t = ntk ? static_cast<T*>(c.out_t) : nullptr;
   a.ldo = c.ldo;
-  const int64_t ntiles = c.symmetric ? tm * (tm + 1) / 2 : tm * tn;
-  size_t lds = TileNT<T, kTile, kTile>::LDS_BYTES;
+  int64_t ntiles = c.symmetric ? tm * (tm + 1) / 2 : tm * tn;
+  a.use_map = 0;
+  a.map = TileMap::make(tm, tn, c.symmetric);
+  if (ctx->xcd_map && ntiles >= 512) {
+    a.use_map = 1;
+    ntiles = a.map.grid;
+  }
+  size_t lds = MainTile<T>::LDS_BYTES;
   const size_t tab_lds = (size_t)prog.nsets * 2 * 2 * kTile * sizeof(T);
   if (tab_lds > lds) lds = tab_lds;
   return launch_build<T>(ctx, a, ntiles, lds, ntk);
