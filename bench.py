@@ -42,6 +42,8 @@ def parse():
     p.add_argument("--cpu-sample-n", type=int, default=4096)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-recursion-probe", action="store_true")
+    p.add_argument("--sharded-path", action="store_true",
+                   help="run the N>1 step (row shard + all-gather + LML) even with one rank (rehearsal on one GPU)")
     return p.parse_args()
 
 
@@ -141,22 +143,24 @@ def main():
     y = ctx.to_device(rng.standard_normal(n).astype(np_dtype))
     lp, quad, logdet, info = C.c_double(), C.c_double(), C.c_double(), C.c_int()
 
-    if world == 1:
+    sharded = world > 1 or args.sharded_path
+    if not sharded:
         def step():
             ctx.call("smn_spr_loss", code, L.NET_MLP, act, nl, 1.0, 1e-8, 1.0, x.ptr, n, d, d, y.ptr, eps, 0.0, 1.0,
                      C.byref(lp), C.byref(quad), C.byref(logdet), C.byref(info))
     else:
-        if n % world:
-            sys.exit("N must be divisible by the number of ranks")
-        rows = n // world
-        kfull = ctx.empty((n, n), np_dtype)
+        from smnngp import sharding
+        rows = sharding.rows_per_rank(n, world)
+        rb, re = sharding.row_shard(n, world, rank)
+        kfull = ctx.empty((sharding.gathered_rows(n, world), n), np_dtype)   # rows >= n are gather padding
         es = np.dtype(np_dtype).itemsize
         mine = C.c_void_p(kfull.ptr.value + rank * rows * n * es)
 
         def step():
-            ctx.call("smn_kernel_mlp_rows", code, L.NET_MLP, act, nl, 1.0, 1e-8, 1.0, x.ptr, n, d, d,
-                     rank * rows, (rank + 1) * rows, L.GET_NNGP, mine, None, n)
-            ctx.call("smn_allgather", code, mine, kfull.ptr, rows * n)
+            if re > rb:
+                ctx.call("smn_kernel_mlp_rows", code, L.NET_MLP, act, nl, 1.0, 1e-8, 1.0, x.ptr, n, d, d,
+                         rb, re, L.GET_NNGP, mine, None, n)
+            ctx.call("smn_allgather", code, mine, kfull.ptr, sharding.chunk_elems(n, world, n))   # in place
             ctx.call("smn_lml", code, kfull.ptr, n, n, y.ptr, eps, 0.0, 1.0, C.byref(lp), C.byref(quad),
                      C.byref(logdet), C.byref(info))
 
@@ -194,7 +198,7 @@ def main():
         peak = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_F64_MFMA_TFLOPS
         per = {k: (v[0] / max(args.steps, 1), v[1] // max(args.steps, 1)) for k, v in prof.items()}
         kp = ((d + 31) // 32 * 32) if args.dtype == "f32" else ((d + 15) // 16 * 16)
-        if world == 1:
+        if not sharded:
             t = n_total // TILE
             build_fl = (t * (t + 1) // 2) * TILE * TILE * 2.0 * kp
         else:
@@ -226,7 +230,7 @@ def main():
                                    % (n, d, nl, args.act),
                        "N": n, "d": d, "layers": nl, "act": args.act, "w_std": 1.0, "b_std": 1e-8, "last_w_std": 1.0,
                        "eps_abs": eps, "flops_counted": flops_counted,
-                       "parallelism": "single GPU" if world == 1 else "row-sharded build x%d + RCCL all-gather + replicated Cholesky" % world},
+                       "parallelism": "single GPU" if not sharded else "row-sharded build x%d + RCCL all-gather + replicated Cholesky" % world},
             "phases_ms": {k: round(v[0], 4) for k, v in per.items()},
             "result": {"logpdf": lp.value, "logdet": logdet.value, "info": info.value},
             "roofline": roof,

@@ -1,11 +1,233 @@
-// cnn.hip — conv-NNGP kernel (experiments/nt_kernels.py:34-45).  Placeholder until the pair-tile
-// kernel lands: reports SMN_ENOTSUP so callers fail loudly instead of silently falling back.
+// cnn.hip — conv-NNGP kernel of experiments/nt_kernels.py:34-45:
+//     L x [Conv(1 ch, 3x3, stride 1, SAME, W_std=w, b_std=b); act];  Flatten;  Dense(last_w, b=0)
+// (neural_tangents stax.Conv / Flatten).  Because there is no pooling before
+// Flatten only same-pixel covariances are needed: for an image pair (n, m) the state is one H x W map
+//     K0[h,w] = sum_c x1[n,h,w,c] x2[m,h,w,c] / C
+//     K <- w^2 * (3x3 zero-padded box SUM of K) / 9 + b^2 ;  K <- act(K; q1[n,h,w], q2[m,h,w])   (per pixel)
+//     out[n,m] = last_w^2 * mean_hw K
+// The N^2 * H * W per-pixel kernel entries can never be materialised (C3: 819 GB in fp64), so each
+// wave carries one pair's map through all layers on chip: the map lives in LDS with a zero halo
+// (ping-pong between layers), lanes own pixels, the 3x3 stencil is 9 LDS reads.  The per-image
+// pre-activation variance maps q~_l[n,h,w] (the same stencil recursion on the diagonal) are computed
+// once per image by conv_q_kernel and streamed from L2.  VALU-bound by construction (a 9-tap sum and
+// an asin per pixel, pair and layer); no MFMA: there is no GEMM here to find.
 #include "internal.hpp"
+#include "nngp_math.hpp"
+
+namespace {
+
+template <typename T>
+__device__ __forceinline__ T rsqrt_any(T x);
+template <>
+__device__ __forceinline__ float rsqrt_any<float>(float x) { return __builtin_amdgcn_rsqf(x); }
+template <>
+__device__ __forceinline__ double rsqrt_any<double>(double x) { return 1.0 / sqrt(x); }
+
+struct ConvProg {
+  int act, layers, H, W, C;
+  double w2, b2, lw2;
+};
+
+// One workgroup per image: Q[img][l][p] = pre-activation variance of layer l at pixel p,
+// diag[img] = last_w^2 * mean_p q_L (the exact K(img, img)).
+template <typename T>
+__global__ void __launch_bounds__(256) conv_q_kernel(const T* __restrict__ x, int64_t n, ConvProg p,
+                                                     T* __restrict__ Q, T* __restrict__ diag) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int H = p.H, W = p.W, HW = H * W, PW = W + 2, PSZ = (H + 2) * PW;
+  double* m0 = reinterpret_cast<double*>(smem);   // padded map, double for the diagonal
+  double* m1 = m0 + PSZ;
+  const int64_t img = blockIdx.x;
+  for (int i = threadIdx.x; i < 2 * PSZ; i += blockDim.x) m0[i] = 0.0;
+  __syncthreads();
+  for (int px = threadIdx.x; px < HW; px += blockDim.x) {
+    const T* xp = x + (img * HW + px) * p.C;
+    double s = 0.0;
+    for (int c = 0; c < p.C; ++c) s += (double)xp[c] * (double)xp[c];
+    m0[(px / W + 1) * PW + px % W + 1] = s / p.C;
+  }
+  __syncthreads();
+  double* cur = m0;
+  double* nxt = m1;
+  for (int l = 0; l < p.layers; ++l) {
+    for (int px = threadIdx.x; px < HW; px += blockDim.x) {
+      const int h = px / W, w = px % W;
+      const double* c = cur + h * PW + w;   // top-left of the 3x3 window in the padded map
+      const double bs = c[0] + c[1] + c[2] + c[PW] + c[PW + 1] + c[PW + 2] + c[2 * PW] + c[2 * PW + 1] + c[2 * PW + 2];
+      const double qt = p.w2 * bs / 9.0 + p.b2;
+      Q[(img * p.layers + l) * HW + px] = (T)qt;
+      const double qa = p.act == 0 ? 0.5 * qt : (2.0 / nngp::kPi) * asin(2.0 * qt / (1.0 + 2.0 * qt));
+      nxt[(h + 1) * PW + w + 1] = qa;
+    }
+    __syncthreads();
+    double* t = cur; cur = nxt; nxt = t;
+  }
+  // mean over pixels (block tree reduction in the free map)
+  double s = 0.0;
+  for (int px = threadIdx.x; px < HW; px += blockDim.x) s += cur[(px / W + 1) * PW + px % W + 1];
+  double* red = m0 + 2 * PSZ;   // 256 doubles of scratch behind the two maps
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = blockDim.x / 2; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) diag[img] = (T)(p.lw2 * red[0] / HW);
+}
+
+template <typename T>
+struct PairArgs {
+  const T* x1; const T* x2; const T* Q1; const T* Q2; const T* diag;
+  int64_t n1, n2; int symmetric, mirror;
+  ConvProg prog;
+  T* out; int64_t ldo; int64_t npairs;
+};
+
+constexpr int kMaxPix = 64;   // pixels per lane held in registers between phases (H*W <= 4096)
+
+// 4 waves per workgroup, one image pair per wave per iteration.
+template <typename T, int ACT>
+__global__ void __launch_bounds__(256) conv_pair_kernel(PairArgs<T> a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const ConvProg& p = a.prog;
+  const int H = p.H, W = p.W, HW = H * W, PW = W + 2, PSZ = (H + 2) * PW;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  T* buf0 = reinterpret_cast<T*>(smem) + (size_t)wave * 2 * PSZ;
+  T* buf1 = buf0 + PSZ;
+  for (int i = lane; i < 2 * PSZ; i += 64) buf0[i] = T(0);   // halo stays zero for the whole kernel
+  const T w2_9 = (T)(p.w2 / 9.0), b2 = (T)p.b2;
+  const T inv_c = (T)(1.0 / p.C);
+  const int64_t stride = (int64_t)gridDim.x * 4;
+  // every wave of the workgroup runs the same number of iterations (barriers inside the loop)
+  const int64_t iters = (a.npairs + stride - 1) / stride;
+  for (int64_t it = 0; it < iters; ++it) {
+    const int64_t pr = (int64_t)blockIdx.x * 4 + wave + it * stride;
+    const bool live = pr < a.npairs;
+    int64_t n = 0, m = 0;
+    if (live) {
+      if (a.symmetric) {
+        int64_t r = (int64_t)((sqrt(8.0 * (double)pr + 1.0) - 1.0) * 0.5);
+        while ((r + 1) * (r + 2) / 2 <= pr) ++r;
+        while (r * (r + 1) / 2 > pr) --r;
+        n = r;
+        m = pr - r * (r + 1) / 2;
+      } else {
+        n = pr / a.n2;
+        m = pr % a.n2;
+      }
+    }
+    // K0 map
+    const T* xa = a.x1 + n * HW * p.C;
+    const T* xb = a.x2 + m * HW * p.C;
+    for (int px = lane; px < HW; px += 64) {
+      T s = T(0);
+      for (int c = 0; c < p.C; ++c) s = fma(xa[px * p.C + c], xb[px * p.C + c], s);
+      buf0[(px / W + 1) * PW + px % W + 1] = live ? s * inv_c : T(0);
+    }
+    __syncthreads();
+    T* cur = buf0;
+    T* nxt = buf1;
+    for (int l = 0; l < p.layers; ++l) {
+      const T* q1 = a.Q1 + (n * p.layers + l) * HW;
+      const T* q2 = a.Q2 + (m * p.layers + l) * HW;
+      for (int px = lane; px < HW; px += 64) {
+        const int h = px / W, w = px % W;
+        const T* c = cur + h * PW + w;
+        const T bs = c[0] + c[1] + c[2] + c[PW] + c[PW + 1] + c[PW + 2] + c[2 * PW] + c[2 * PW + 1] + c[2 * PW + 2];
+        const T kt = fma(w2_9, bs, b2);
+        T kn;
+        if (ACT == 0) {
+          const T pp = q1[px] * q2[px];
+          const T rp = pp > T(0) ? rsqrt_any<T>(pp) : T(0);
+          kn = nngp::relu_map<T, false>(kt, rp, pp * rp * T(1.0 / (2.0 * nngp::kPi))).k;
+        } else {
+          const T pp = (T(1) + T(2) * q1[px]) * (T(1) + T(2) * q2[px]);
+          kn = nngp::erf_map<T, false>(kt, rsqrt_any<T>(pp), T(0)).k;
+        }
+        nxt[(h + 1) * PW + w + 1] = kn;
+      }
+      __syncthreads();
+      T* t = cur; cur = nxt; nxt = t;
+    }
+    // Flatten (mean over pixels) + last Dense
+    T s = T(0);
+    for (int px = lane; px < HW; px += 64) s += cur[(px / W + 1) * PW + px % W + 1];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (live && lane == 0) {
+      T v = (T)p.lw2 * s / (T)HW;
+      if (a.symmetric && n == m) v = a.diag[n];
+      a.out[n * a.ldo + m] = v;
+      if (a.symmetric && a.mirror && n != m) a.out[m * a.ldo + n] = v;
+    }
+    __syncthreads();   // the maps are rewritten by the next pair
+  }
+}
+
+template <typename T>
+int cnn_t(smn_ctx* ctx, int act, int layers, double w, double b, double lw, const void* x1, int64_t n1,
+          const void* x2, int64_t n2, int64_t H, int64_t W, int64_t C, int fill, void* out, int64_t ldk) {
+  const bool sym = x2 == nullptr;
+  if (sym) n2 = n1;
+  ConvProg p{act, layers, (int)H, (int)W, (int)C, w * w, b * b, lw * lw};
+  const int64_t HW = H * W;
+  const size_t psz = (size_t)(H + 2) * (W + 2);
+  const size_t lds_q = (2 * psz + 256) * sizeof(double);
+  const size_t lds_p = 4 * 2 * psz * sizeof(T);
+  if (lds_q > 160 * 1024 || lds_p > 160 * 1024)
+    return smn_fail(ctx, SMN_ENOTSUP, "smn_kernel_cnn: image %lldx%lld too large for the on-chip pair map", (long long)H, (long long)W);
+  // tables: Q1 [n1][L][HW], diag1 [n1] (+ Q2, diag2)
+  const size_t qn1 = (size_t)n1 * (size_t)(layers > 0 ? layers : 1) * HW, qn2 = sym ? 0 : (size_t)n2 * (size_t)(layers > 0 ? layers : 1) * HW;
+  void* tv = nullptr;
+  SMN_TRY(smn_workspace(ctx, 1, sizeof(T) * (qn1 + qn2 + (size_t)n1 + (size_t)n2), &tv));
+  T* Q1 = static_cast<T*>(tv);
+  T* Q2 = sym ? Q1 : Q1 + qn1;
+  T* d1 = Q1 + qn1 + qn2;
+  T* d2 = d1 + n1;
+  {
+    ProfScope ps(ctx, PROF_PREP, ctx->stream);
+    SMN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_q_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q));
+    hipLaunchKernelGGL(conv_q_kernel<T>, dim3((unsigned)n1), dim3(256), lds_q, ctx->stream,
+                       static_cast<const T*>(x1), n1, p, Q1, d1);
+    if (!sym)
+      hipLaunchKernelGGL(conv_q_kernel<T>, dim3((unsigned)n2), dim3(256), lds_q, ctx->stream,
+                         static_cast<const T*>(x2), n2, p, Q2, d2);
+  }
+  SMN_CHECK_LAUNCH(ctx);
+  PairArgs<T> a;
+  a.x1 = static_cast<const T*>(x1); a.x2 = sym ? a.x1 : static_cast<const T*>(x2);
+  a.Q1 = Q1; a.Q2 = Q2; a.diag = d1; a.n1 = n1; a.n2 = n2;
+  a.symmetric = sym ? 1 : 0; a.mirror = (sym && fill == SMN_FILL_FULL) ? 1 : 0;
+  a.prog = p; a.out = static_cast<T*>(out); a.ldo = ldk;
+  a.npairs = sym ? n1 * (n1 + 1) / 2 : n1 * n2;
+  int64_t blocks = (a.npairs + 3) / 4;
+  if (blocks > 256 * 8) blocks = 256 * 8;   // persistent-ish: waves stride over the pair list
+  {
+    ProfScope ps(ctx, PROF_BUILD, ctx->stream);
+    if (act == SMN_ACT_RELU) {
+      SMN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pair_kernel<T, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p));
+      hipLaunchKernelGGL((conv_pair_kernel<T, 0>), dim3((unsigned)blocks), dim3(256), lds_p, ctx->stream, a);
+    } else {
+      SMN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pair_kernel<T, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p));
+      hipLaunchKernelGGL((conv_pair_kernel<T, 1>), dim3((unsigned)blocks), dim3(256), lds_p, ctx->stream, a);
+    }
+  }
+  SMN_CHECK_LAUNCH(ctx);
+  return SMN_OK;
+}
+
+}  // namespace
 
 extern "C" int smn_kernel_cnn(smn_ctx* ctx, int dtype, int act, int num_hiddens, double w_std, double b_std,
                               double last_w_std, const void* x1_d, int64_t n1, const void* x2_d, int64_t n2, int64_t H,
                               int64_t W, int64_t C, int fill, void* nngp_d, int64_t ldk) {
-  (void)dtype; (void)act; (void)num_hiddens; (void)w_std; (void)b_std; (void)last_w_std; (void)x1_d; (void)n1;
-  (void)x2_d; (void)n2; (void)H; (void)W; (void)C; (void)fill; (void)nngp_d; (void)ldk;
-  return smn_fail(ctx, SMN_ENOTSUP, "smn_kernel_cnn: not implemented yet");
+  if (!ctx || !x1_d || !nngp_d) return SMN_EINVAL;
+  if (dtype != SMN_F32 && dtype != SMN_F64) return smn_fail(ctx, SMN_EINVAL, "bad dtype %d", dtype);
+  if (act != SMN_ACT_RELU && act != SMN_ACT_ERF) return smn_fail(ctx, SMN_EINVAL, "Unsupported act %d", act);
+  if (n1 <= 0 || (x2_d && n2 <= 0) || H <= 0 || W <= 0 || C <= 0 || num_hiddens < 0)
+    return smn_fail(ctx, SMN_EINVAL, "smn_kernel_cnn: bad sizes");
+  if (H * W > 64 * kMaxPix) return smn_fail(ctx, SMN_ENOTSUP, "smn_kernel_cnn: H*W > %d", 64 * kMaxPix);
+  if (dtype == SMN_F64)
+    return cnn_t<double>(ctx, act, num_hiddens, w_std, b_std, last_w_std, x1_d, n1, x2_d, n2, H, W, C, fill, nngp_d, ldk);
+  return cnn_t<float>(ctx, act, num_hiddens, w_std, b_std, last_w_std, x1_d, n1, x2_d, n2, H, W, C, fill, nngp_d, ldk);
 }

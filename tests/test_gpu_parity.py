@@ -122,6 +122,40 @@ def test_row_shard_equals_rows_of_full_kernel(L, ctx, dtype):
         assert relerr(out.numpy(), ref[rb:re]) < RTOL[dtype]
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("act", ["relu", "erf"])
+@pytest.mark.parametrize("shape,layers", [((7, 5, 4, 3), 2), ((9, 8, 8, 1), 4), ((5, 1, 1, 6), 3), ((3, 32, 32, 3), 1)])
+def test_cnn_kernel(dtype, act, shape, layers):
+    """get_cnn_kernel (nt_kernels.py:34-45): symmetric, cross and odd image shapes vs the oracle."""
+    from smnngp import nt_kernels
+    rng = np.random.default_rng(sum(shape))
+    x = rng.standard_normal(shape).astype(dtype)
+    x2 = rng.standard_normal((4,) + shape[1:]).astype(dtype)
+    kfn = nt_kernels.get_cnn_kernel(layers, act=act, w_std=1.3, b_std=0.2, last_w_std=0.9)
+    k = np.asarray(kfn(x, None, get="nngp"))
+    ref = O.cnn_kernel(x.astype(np.float64), None, layers, act, 1.3, 0.2, 0.9)
+    assert k.shape == (shape[0], shape[0]) and relerr(k, ref) < RTOL[dtype]
+    assert np.array_equal(k, k.T)
+    kc = np.asarray(kfn(x, x2, get="nngp"))
+    refc = O.cnn_kernel(x.astype(np.float64), x2.astype(np.float64), layers, act, 1.3, 0.2, 0.9)
+    assert kc.shape == (shape[0], 4) and relerr(kc, refc) < RTOL[dtype]
+    with pytest.raises(NotImplementedError):
+        kfn(x, None, get="ntk")
+
+
+def test_cnn_kernel_feeds_the_same_inference_heads():
+    """SVSP-style consumers (spax/models.py:38-43) and NNGPKernel.predict use the conv kernel through the
+    generic kernel_fn path: joint kernel -> smn_predict."""
+    from smnngp import nt_kernels, predict
+    rng = np.random.default_rng(77)
+    x = rng.standard_normal((20, 6, 6, 2)); xt = rng.standard_normal((5, 6, 6, 2)); y = rng.standard_normal((20, 2))
+    kfn = nt_kernels.get_cnn_kernel(2, act="relu", w_std=1.2, b_std=0.1, last_w_std=1.0)
+    mean, cov = predict.gradient_descent_mse_ensemble(kfn, x, y, diag_reg=1e-3)(x_test=xt)
+    kw = dict(num_hiddens=2, act="relu", w_std=1.2, b_std=0.1, last_w_std=1.0)
+    rm, rc = O.predict(O.cnn_kernel(x, None, **kw), O.cnn_kernel(xt, x, **kw), O.cnn_kernel(xt, None, **kw), y, 1e-3)
+    assert relerr(np.asarray(mean), rm) < 1e-7 and relerr(np.asarray(cov), rc) < 1e-7
+
+
 # ----------------------------------------------------------------------------- factorisation
 def _spd(rng, n, dtype, cond=1e3):
     a = rng.standard_normal((n, n))
