@@ -205,8 +205,9 @@ def main():
             build_fl = ((n // world + TILE - 1) // TILE) * (n // TILE) * TILE * TILE * 2.0 * kp
         trail_ms = per["trail"][0]
         roof = {
-            "kernel": "update_kernel<%s,1> (Cholesky trailing update C -= P P^T, K=256, lower 128x128 tiles)" % (
-                "float" if args.dtype == "f32" else "double"),
+            "kernel": ("trail_kernel<float> (persistent) + update_kernel<float,1> (launches under 512 tiles)"
+                       if args.dtype == "f32" else "update_kernel<double,1>")
+                      + ": Cholesky trailing update C -= P P^T, K=256, lower 128x128 tiles",
             "bound": "mfma",
             "achieved": trail_fl / (trail_ms * 1e-3) / 1e12 if trail_ms > 0 else None,
             "peak": peak, "unit": "TFLOP/s",

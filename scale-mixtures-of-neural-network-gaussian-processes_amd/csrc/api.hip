@@ -163,8 +163,16 @@ extern "C" int smn_ctx_create(int device_id, smn_ctx** out) {
   c->device = device_id;
   if (const char* e = getenv("SMN_LOOKAHEAD")) c->lookahead = e[0] == '1';
   if (const char* e = getenv("SMN_XCD_MAP")) c->xcd_map = e[0] == '1';
+  if (const char* e = getenv("SMN_PERSISTENT")) c->persistent_trail = e[0] != '0';
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0)
+      c->num_cu = prop.multiProcessorCount;
+  }
+  int prio_lo = 0, prio_hi = 0;   // the look-ahead stream carries the critical path: highest priority
+  (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
   bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
-            hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) == hipSuccess &&
+            hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_hi) == hipSuccess &&
             hipEventCreateWithFlags(&c->ev_a, hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&c->ev_b, hipEventDisableTiming) == hipSuccess &&
             hipEventCreate(&c->ev_t0) == hipSuccess && hipEventCreate(&c->ev_t1) == hipSuccess &&

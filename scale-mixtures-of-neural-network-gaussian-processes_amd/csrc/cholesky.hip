@@ -30,10 +30,13 @@ constexpr int MP = 8;    // micro-panel width of the in-LDS factorisation
 
 template <typename T>
 struct PanelCfg;
+#ifndef SMN_PANEL_XR
+#define SMN_PANEL_XR 128   // build-time: 32 shrinks the panel workgroup to 85 KB of LDS (look-ahead co-residency)
+#endif
 template <>
 struct PanelCfg<float> {
-  static constexpr int XR = 128;       // appended rows per workgroup
-  static constexpr int THREADS = 256;  // one thread per LDS row
+  static constexpr int XR = SMN_PANEL_XR;                     // appended rows per workgroup (multiple of 32)
+  static constexpr int THREADS = (PB + XR + 63) / 64 * 64;    // one thread per LDS row, whole waves
   static constexpr int LD = PB + 4;    // row stride (elements): 16-byte aligned rows, b128 reads conflict-free
 };
 template <>
@@ -290,6 +293,111 @@ __global__ void __launch_bounds__(256, sizeof(T) == 8 ? 1 : 2) update_kernel(Upd
       }
 }
 
+// Persistent form of the trailing update (lower tiles, f32).  With K = 256 a tile is only 8 K-steps,
+// so in the one-tile-per-workgroup kernel above the C read, the first operand fetch, the store and the
+// workgroup turn-around are ~30 % of a tile's life.  Here a workgroup walks tiles blockIdx.x,
+// blockIdx.x + gridDim.x, ... as ONE continuous stream of K-steps: the operands of the next tile's
+// first step and its C block (into a second accumulator-shaped register set) are fetched during the
+// current tile's last step, so the MFMA stream never waits at a tile boundary.
+template <typename T>
+__global__ void __launch_bounds__(256, 2) trail_kernel(UpdArgs<T> u, int ntiles) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using Tile = TileNT<T, kTile, kTile, 2>;
+  using M = typename Tile::M;
+  using vec_t = typename Tile::vec_t;
+  using acc_t = typename Tile::acc_t;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int lrow = tid >> 3, lchunk = tid & 7;
+  const int wpos = lrow * Tile::ROWB + ((lchunk ^ ((lrow >> 1) & 7)) << 4);
+  const int nk = u.K / M::BK;
+  const int G = gridDim.x;
+  const int64_t lda = u.lda;
+  T* const a = u.a;
+  Tile t;
+  vec_t ra[Tile::PA], rb[Tile::PB];
+
+  auto origin = [&](int tl, int64_t& row0, int64_t& col0) {
+    int tr, tc;
+    tri_decode(tl, tr, tc);
+    row0 = u.r0 + (int64_t)tr * kTile;
+    col0 = u.c0 + (int64_t)tc * kTile;
+  };
+  auto gload = [&](int64_t row0, int64_t col0, int kt) {
+    const T* ga = a + (row0 + lrow) * lda + u.k0 + kt * M::BK + lchunk * M::VEC;
+    const T* gb = a + (col0 + lrow) * lda + u.k0 + kt * M::BK + lchunk * M::VEC;
+#pragma unroll
+    for (int p = 0; p < Tile::PA; ++p) ra[p] = *reinterpret_cast<const vec_t*>(ga + (int64_t)(32 * p) * lda);
+#pragma unroll
+    for (int p = 0; p < Tile::PB; ++p) rb[p] = *reinterpret_cast<const vec_t*>(gb + (int64_t)(32 * p) * lda);
+  };
+  auto swrite = [&](int buf) {
+    char* st = smem + buf * Tile::STAGE;
+#pragma unroll
+    for (int p = 0; p < Tile::PA; ++p) *reinterpret_cast<vec_t*>(st + wpos + 32 * p * Tile::ROWB) = ra[p];
+#pragma unroll
+    for (int p = 0; p < Tile::PB; ++p) *reinterpret_cast<vec_t*>(st + Tile::A_BYTES + wpos + 32 * p * Tile::ROWB) = rb[p];
+  };
+  auto cload = [&](int64_t row0, int64_t col0, acc_t (&dst)[Tile::MT][Tile::NT]) {   // dst = -C
+#pragma unroll
+    for (int m = 0; m < Tile::MT; ++m)
+#pragma unroll
+      for (int n = 0; n < Tile::NT; ++n)
+#pragma unroll
+        for (int i = 0; i < M::ACC; ++i)
+          dst[m][n][i] = -a[(row0 + wr * Tile::WM + m * M::TM + M::acc_row(lane, i)) * lda + col0 + wc * Tile::WN +
+                            n * M::TN + M::acc_col(lane)];
+  };
+
+  int tile = blockIdx.x;
+  if (tile >= ntiles) return;
+  int64_t row0, col0;
+  origin(tile, row0, col0);
+  t.zero();
+  gload(row0, col0, 0);
+  swrite(0);
+  __syncthreads();
+  int cur = 0;
+  while (true) {
+    const int nxt = tile + G;
+    const bool has_next = nxt < ntiles;
+    int64_t nrow0 = 0, ncol0 = 0;
+    if (has_next) origin(nxt, nrow0, ncol0);
+    for (int kt = 0; kt + 1 < nk; ++kt) {
+      gload(row0, col0, kt + 1);
+      t.compute(smem + cur * Tile::STAGE, lane, wr, wc);
+      swrite(cur ^ 1);
+      __syncthreads();
+      cur ^= 1;
+    }
+    // last K-step (peeled so that `cn` is live only from here to the store below)
+    if (has_next) gload(nrow0, ncol0, 0);     // the next tile's first K-step rides under this tile's last one
+    t.compute(smem + cur * Tile::STAGE, lane, wr, wc);
+    if (has_next) swrite(cur ^ 1);
+    __builtin_amdgcn_sched_barrier(0);        // keep the C loads BELOW the MFMAs and the staging writes:
+    acc_t cn[Tile::MT][Tile::NT];             //   staging registers are free again, C (negated) goes in flight
+    cload(row0, col0, cn);                    //   across the barrier; the co-resident workgroup covers the wait
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    cur ^= 1;
+    // C_new = C - acc = -(cn + acc)
+#pragma unroll
+    for (int m = 0; m < Tile::MT; ++m)
+#pragma unroll
+      for (int n = 0; n < Tile::NT; ++n)
+#pragma unroll
+        for (int i = 0; i < M::ACC; ++i) {
+          a[(row0 + wr * Tile::WM + m * M::TM + M::acc_row(lane, i)) * lda + col0 + wc * Tile::WN + n * M::TN +
+            M::acc_col(lane)] = -(cn[m][n][i] + t.acc[m][n][i]);
+          t.acc[m][n][i] = T(0);
+        }
+    if (!has_next) break;
+    tile = nxt;
+    row0 = nrow0;
+    col0 = ncol0;
+  }
+}
+
 template <typename T>
 __global__ void diag_trace_kernel(const T* __restrict__ a, int64_t lda, int64_t n, double* __restrict__ out) {
   // single block; deterministic tree
@@ -331,6 +439,16 @@ int launch_update(smn_ctx* ctx, hipStream_t st, T* a, int64_t lda, int64_t r0, i
     nt = u.map.grid;
   }
   const size_t lds = MainTile<T>::LDS_BYTES;
+  if constexpr (sizeof(T) == 4) {
+    if (tag == 1 && lower && !u.use_map && ctx->persistent_trail && nt > 2 * ctx->num_cu) {
+      // persistent walk over the lower tiles, two workgroups per CU
+      const size_t plds = TileNT<T, kTile, kTile, 2>::LDS_BYTES;
+      ProfScope ps(ctx, PROF_TRAIL, st);
+      hipLaunchKernelGGL(trail_kernel<T>, dim3((unsigned)(2 * ctx->num_cu)), dim3(256), plds, st, u, (int)nt);
+      SMN_CHECK_LAUNCH(ctx);
+      return SMN_OK;
+    }
+  }
   {
     ProfScope ps(ctx, tag ? PROF_TRAIL : PROF_STRIP, st);
     if (tag) {
@@ -376,6 +494,10 @@ int set_lds_attrs(smn_ctx* ctx) {
   SMN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(update_kernel<T, 1>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)MainTile<T>::LDS_BYTES));
+  if constexpr (sizeof(T) == 4)
+    SMN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(trail_kernel<T>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)TileNT<T, kTile, kTile, 2>::LDS_BYTES));
   done = true;
   return SMN_OK;
 }

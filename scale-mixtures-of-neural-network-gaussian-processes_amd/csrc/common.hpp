@@ -33,6 +33,8 @@ struct smn_ctx {
   std::vector<int> prof_cat;         // category of pair i
   size_t prof_used = 0;              // events handed out
   bool lookahead = false;            // Cholesky look-ahead on stream2 (env SMN_LOOKAHEAD=1)
+  int num_cu = 256;                  // hipDeviceProp_t::multiProcessorCount
+  bool persistent_trail = true;      // persistent trailing-update kernel (env SMN_PERSISTENT=0 disables)
   bool xcd_map = false;              // XCD-aware patch tile order (env SMN_XCD_MAP=1): measured 2-6 % SLOWER
                                      // than the linear order on C4 (profiles/README.md), so off by default
 };

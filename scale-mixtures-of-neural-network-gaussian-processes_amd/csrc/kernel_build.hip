@@ -46,6 +46,8 @@ __global__ void diag_tables_kernel(const double* __restrict__ q0, int64_t n, Lay
     q = p.w2 * q + p.b2;
     th = q;
   }
+  const double w = sqrt(p.w2), b = sqrt(p.b2);
+  double s_prev = 1.0 / w;   // FAST: u^0 = w r^0 (s_prev * w == 1)
   for (int s = 0; s < p.nsets; ++s) {
     const double qt = (p.net == NET_MLP) ? p.w2 * q + p.b2 : q;   // pre-activation variance
     const double tht = (p.net == NET_MLP) ? qt + p.w2 * th : th;
@@ -61,8 +63,14 @@ __global__ void diag_tables_kernel(const double* __restrict__ q0, int64_t n, Lay
       qa = (2.0 / nngp::kPi) * asin(2.0 * qt / (1.0 + 2.0 * qt));
       kdot = 4.0 / (nngp::kPi * sqrt(1.0 + 4.0 * qt));
     }
-    tab[(int64_t)(2 * s) * ldt + i] = (T)r;
-    tab[(int64_t)(2 * s + 1) * ldt + i] = (T)sv;
+    if (p.fast) {   // correlation-space tables (layer_prog.hpp): u = w s_prev r, v = b r
+      tab[(int64_t)(2 * s) * ldt + i] = (T)(s == 0 ? w * r : w * s_prev * r);
+      tab[(int64_t)(2 * s + 1) * ldt + i] = (T)(b * r);
+      s_prev = sv;
+    } else {
+      tab[(int64_t)(2 * s) * ldt + i] = (T)r;
+      tab[(int64_t)(2 * s + 1) * ldt + i] = (T)sv;
+    }
     if (p.net == NET_MLP || s == p.nsets - 1) {
       q = qa;
       th = tht * kdot;
@@ -77,7 +85,8 @@ __global__ void diag_tables_kernel(const double* __restrict__ q0, int64_t n, Lay
     th = q + p.lw2 * th;
   }
   dg[i] = (T)q;
-  dgt[i] = (T)th;
+  // FAST: sigma = last_w * s^{L-1} (no hidden layer: K = last_w^2 K0, sigma = last_w)
+  dgt[i] = p.fast ? (T)(sqrt(p.lw2) * (p.nsets > 0 ? s_prev : 1.0)) : (T)th;
 }
 
 // ------------------------------------------------------------------ fused Gram + recursion
@@ -118,12 +127,15 @@ __global__ void __launch_bounds__(256, (NTK || sizeof(T) == 8) ? 1 : 2) build_ke
   const int nsets = a.prog.nsets;
 
   // stage the per-row / per-column layer tables of this tile in LDS (mainloop ended on a barrier)
+  constexpr bool FAST = ElemProg<T, NET, ACT, NTK>::FAST;
+  const int trows = nsets * 2 + (FAST ? 1 : 0);   // FAST: one more row, sigma (kept in the NTK-diagonal slot)
   T* srow = reinterpret_cast<T*>(smem);
-  T* scol = srow + nsets * 2 * kTile;
-  for (int idx = tid; idx < nsets * 2 * kTile; idx += 256) {
+  T* scol = srow + trows * kTile;
+  for (int idx = tid; idx < trows * kTile; idx += 256) {
     const int s2 = idx / kTile, r = idx % kTile;
-    srow[idx] = a.tab1[(int64_t)s2 * a.ldt1 + row0 + r];
-    scol[idx] = a.tab2[(int64_t)s2 * a.ldt2 + col0 + r];
+    const int g2 = s2 < nsets * 2 ? s2 : nsets * 2 + 1;
+    srow[idx] = a.tab1[(int64_t)g2 * a.ldt1 + row0 + r];
+    scol[idx] = a.tab2[(int64_t)g2 * a.ldt2 + col0 + r];
   }
   __syncthreads();
 
@@ -177,7 +189,10 @@ __global__ void __launch_bounds__(256, (NTK || sizeof(T) == 8) ? 1 : 2) build_ke
         const int64_t gr = row0 + wr * Tile::WM + m * M::TM + M::acc_row(lane, i);
         const int64_t gc = col0 + wc * Tile::WN + n * M::TN + M::acc_col(lane);
         T k = t.acc[m][n][i], h = th[m][n][i];
-        prog.post(k, h);
+        T sig = T(0);
+        if (FAST)
+          sig = srow[nsets * 2 * kTile + (int)(gr - row0)] * scol[nsets * 2 * kTile + (int)(gc - col0)];
+        prog.post(k, h, sig);
         if (a.exact_diag && gr + a.row_off == gc + a.col_off) {
           k = a.dg[gr];
           if (NTK) h = a.dgt[gr];
@@ -215,80 +230,119 @@ struct RecArgs {
 };
 
 // Block = 4 waves; blockIdx.x -> strip of 64*VEC columns, blockIdx.y -> group of rows.  A wave
-// streams one row segment at a time with 16-byte loads/stores; column tables live in LDS (read as
-// one b128 per table per layer), row tables are wave-uniform scalar loads.
+// streams one row segment at a time with 16-byte loads/stores, the next row's load in flight under
+// the current row's math; column tables (one b128 per table per layer) and row tables (broadcast
+// reads) both live in LDS, so the layer loop touches no global memory.
 template <typename T, int NET, int ACT, bool NTK>
 __global__ void __launch_bounds__(256) recursion_kernel(RecArgs<T> a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int VEC = 16 / sizeof(T);
-  constexpr int COLS = 64 * VEC;
+  constexpr int COLS = 256 * VEC;   // the 4 waves sit side by side on ONE row: 4 KiB contiguous per row visit
   using vec_t = typename Mfma<T>::vec_t;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tid = threadIdx.x;
   const int nsets = a.prog.nsets;
   const int64_t col0 = (int64_t)blockIdx.x * COLS;
-  T* scol = reinterpret_cast<T*>(smem);   // [nsets][2][COLS]
-  for (int idx = tid; idx < nsets * 2 * COLS; idx += 256) {
+  const int RB = a.rows_per_block;
+  constexpr bool FAST = ElemProg<T, NET, ACT, NTK>::FAST;
+  const int trows = nsets * 2 + 1;        // + sigma (FAST); the slot is staged but unused otherwise
+  T* scol = reinterpret_cast<T*>(smem);   // [trows][COLS]
+  T* srow = scol + trows * COLS;          // [trows][RB]: row factors too, so no global load sits in the layer loop
+  const int64_t rbeg = (int64_t)blockIdx.y * RB;
+  const int64_t rend = min(rbeg + RB, a.n1);
+  for (int idx = tid; idx < trows * COLS; idx += 256) {
     const int s2 = idx / COLS, c = idx % COLS;
+    const int g2 = s2 < nsets * 2 ? s2 : nsets * 2 + 1;
     const int64_t gc = col0 + c;
-    scol[idx] = gc < a.n2 ? a.tab2[(int64_t)s2 * a.ldt2 + gc] : T(0);
+    scol[idx] = gc < a.n2 ? a.tab2[(int64_t)g2 * a.ldt2 + gc] : T(0);
+  }
+  for (int idx = tid; idx < trows * RB; idx += 256) {
+    const int s2 = idx / RB, r = idx % RB;
+    const int g2 = s2 < nsets * 2 ? s2 : nsets * 2 + 1;
+    srow[idx] = rbeg + r < rend ? a.tab1[(int64_t)g2 * a.ldt1 + rbeg + r] : T(0);
   }
   __syncthreads();
   const ElemProg<T, NET, ACT, NTK> prog(a.prog);
-  const int64_t gc = col0 + lane * VEC;
-  const int64_t rbeg = (int64_t)blockIdx.y * a.rows_per_block;
-  const int64_t rend = min(rbeg + a.rows_per_block, a.n1);
+  const int64_t gc = col0 + tid * VEC;
   const bool full = gc + VEC <= a.n2;
-  for (int64_t row = rbeg + wave; row < rend; row += 4) {
-    vec_t kv;
+  auto load_row = [&](int64_t row) {
+    vec_t v;
     if (full) {
-      kv = *reinterpret_cast<const vec_t*>(a.k0 + row * a.ldk0 + gc);
+      v = *reinterpret_cast<const vec_t*>(a.k0 + row * a.ldk0 + gc);
     } else {
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) kv[e] = gc + e < a.n2 ? a.k0[row * a.ldk0 + gc + e] : T(0);
+      for (int e = 0; e < VEC; ++e) v[e] = gc + e < a.n2 ? a.k0[row * a.ldk0 + gc + e] : T(0);
     }
-    vec_t hv;
+    return v;
+  };
+  // NR rows per iteration: the column tables are read once per layer for both rows, and the NR * VEC
+  // independent element chains per lane give the VALU enough ILP at the 2-4 waves per SIMD the LDS
+  // tables leave room for.  The next NR rows are in flight under the current ones.  (RB % NR == 0.)
+  constexpr int NR = 2;
+  vec_t nx[NR];
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) {
-      T k = kv[e], h = T(0);
-      prog.pre(k, h);
-      kv[e] = k;
-      hv[e] = h;
-    }
-    for (int s = 0; s < nsets; ++s) {
-      const T ri = a.tab1[(int64_t)(2 * s) * a.ldt1 + row];
-      const T si = a.tab1[(int64_t)(2 * s + 1) * a.ldt1 + row];
-      const vec_t cr = *reinterpret_cast<const vec_t*>(scol + (2 * s) * COLS + lane * VEC);
-      const vec_t cs = *reinterpret_cast<const vec_t*>(scol + (2 * s + 1) * COLS + lane * VEC);
+  for (int r = 0; r < NR; ++r) nx[r] = rbeg + r < rend ? load_row(rbeg + r) : vec_t{};
+  for (int64_t row = rbeg; row < rend; row += NR) {
+    vec_t kv[NR], hv[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) kv[r] = nx[r];
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+      if (row + NR + r < rend) nx[r] = load_row(row + NR + r);
+    const int lr = (int)(row - rbeg);
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
-        T k = kv[e], h = hv[e];
-        prog.step(s, k, h, ri * cr[e], si * cs[e]);
-        kv[e] = k;
-        hv[e] = h;
+        T k = kv[r][e], h = T(0);
+        prog.pre(k, h);
+        kv[r][e] = k;
+        hv[r][e] = h;
       }
-    }
+    for (int s = 0; s < nsets; ++s) {
+      const vec_t cr = *reinterpret_cast<const vec_t*>(scol + (2 * s) * COLS + tid * VEC);
+      const vec_t cs = *reinterpret_cast<const vec_t*>(scol + (2 * s + 1) * COLS + tid * VEC);
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) {
-      T k = kv[e], h = hv[e];
-      prog.post(k, h);
-      if (a.exact_diag && row == gc + e) {
-        k = a.dg[row];
-        if (NTK) h = a.dgt[row];
-      }
-      kv[e] = k;
-      hv[e] = h;
-    }
-    if (full) {
-      if (a.out_k) *reinterpret_cast<vec_t*>(a.out_k + row * a.ldo + gc) = kv;
-      if (NTK && a.out_t) *reinterpret_cast<vec_t*>(a.out_t + row * a.ldo + gc) = hv;
-    } else {
+      for (int r = 0; r < NR; ++r) {
+        const T ri = srow[(2 * s) * RB + lr + r];
+        const T si = srow[(2 * s + 1) * RB + lr + r];
 #pragma unroll
-      for (int e = 0; e < VEC; ++e)
-        if (gc + e < a.n2) {
-          if (a.out_k) a.out_k[row * a.ldo + gc + e] = kv[e];
-          if (NTK && a.out_t) a.out_t[row * a.ldo + gc + e] = hv[e];
+        for (int e = 0; e < VEC; ++e) {
+          T k = kv[r][e], h = hv[r][e];
+          prog.step(s, k, h, ri * cr[e], si * cs[e]);
+          kv[r][e] = k;
+          hv[r][e] = h;
         }
+      }
+    }
+    vec_t sgc = vec_t{};
+    if (FAST) sgc = *reinterpret_cast<const vec_t*>(scol + (2 * nsets) * COLS + tid * VEC);
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const int64_t rr = row + r;
+      if (rr >= rend) break;
+      const T sgr = FAST ? srow[(2 * nsets) * RB + lr + r] : T(0);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        T k = kv[r][e], h = hv[r][e];
+        prog.post(k, h, sgr * sgc[e]);
+        if (a.exact_diag && rr == gc + e) {
+          k = a.dg[rr];
+          if (NTK) h = a.dgt[rr];
+        }
+        kv[r][e] = k;
+        hv[r][e] = h;
+      }
+      if (full) {
+        if (a.out_k) *reinterpret_cast<vec_t*>(a.out_k + rr * a.ldo + gc) = kv[r];
+        if (NTK && a.out_t) *reinterpret_cast<vec_t*>(a.out_t + rr * a.ldo + gc) = hv[r];
+      } else {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e)
+          if (gc + e < a.n2) {
+            if (a.out_k) a.out_k[rr * a.ldo + gc + e] = kv[r][e];
+            if (NTK && a.out_t) a.out_t[rr * a.ldo + gc + e] = hv[r][e];
+          }
+      }
     }
   }
 }
@@ -307,7 +361,14 @@ int make_prog(smn_ctx* ctx, const BuildSpec& s, LayerProg* p) {
   p->w2 = s.w_std * s.w_std;
   p->b2 = s.b_std * s.b_std;
   p->lw2 = s.last_w_std * s.last_w_std;
+  p->fast = 0;
   return SMN_OK;
+}
+
+// The launched kernel template decides FAST at compile time (layer_prog.hpp); the tables must agree.
+template <typename T>
+void set_fast(LayerProg* p, bool ntk) {
+  p->fast = (sizeof(T) == 4 && p->net == NET_MLP && p->act == ACT_RELU && !ntk) ? 1 : 0;
 }
 
 template <typename T, int NET, int ACT, bool NTK>
@@ -351,7 +412,8 @@ int run_build_t(smn_ctx* ctx, const BuildCall& c) {
     return smn_fail(ctx, SMN_EINVAL, "run_build: operands not padded");
   const bool ntk = (c.get_mask & SMN_GET_NTK) != 0;
   if (ntk && prog.net == NET_NONE) return smn_fail(ctx, SMN_EINVAL, "NTK of a bare Gram");
-  // tables: [2*nsets + 1] rows of length rows1 (+ rows2 when not symmetric)
+  set_fast<T>(&prog, ntk);
+  // tables: [2*nsets + 2] rows of length rows1 (+ rows2 when not symmetric)
   const int trows = 2 * prog.nsets + 2;
   const int64_t tlen = c.symmetric ? c.rows1 : c.rows1 + c.rows2;
   void* tabv = nullptr;
@@ -390,7 +452,7 @@ int run_build_t(smn_ctx* ctx, const BuildCall& c) {
     ntiles = a.map.grid;
   }
   size_t lds = MainTile<T>::LDS_BYTES;
-  const size_t tab_lds = (size_t)prog.nsets * 2 * 2 * kTile * sizeof(T);
+  const size_t tab_lds = (size_t)(prog.nsets * 2 + 1) * 2 * kTile * sizeof(T);
   if (tab_lds > lds) lds = tab_lds;
   return launch_build<T>(ctx, a, ntiles, lds, ntk);
 }
@@ -437,6 +499,7 @@ int recursion_t(smn_ctx* ctx, const BuildSpec& spec, const void* k0, int64_t n1,
   SMN_TRY(make_prog(ctx, spec, &prog));
   if (prog.net == NET_NONE) return smn_fail(ctx, SMN_EINVAL, "recursion needs a net");
   const bool want_ntk = (get_mask & SMN_GET_NTK) != 0;
+  set_fast<T>(&prog, want_ntk);
   const int trows = 2 * prog.nsets + 2;
   const int64_t tlen = n1 + n2;
   void* tabv = nullptr;
@@ -460,10 +523,10 @@ int recursion_t(smn_ctx* ctx, const BuildSpec& spec, const void* k0, int64_t n1,
   a.prog = prog; a.exact_diag = symmetric;
   a.out_k = (get_mask & SMN_GET_NNGP) ? static_cast<T*>(nngp) : nullptr;
   a.out_t = want_ntk ? static_cast<T*>(ntk) : nullptr;
-  a.ldo = ldk; a.rows_per_block = 64;
-  constexpr int COLS = 64 * (16 / sizeof(T));
+  a.ldo = ldk; a.rows_per_block = 32;
+  constexpr int COLS = 256 * (16 / sizeof(T));
   dim3 grid((unsigned)((n2 + COLS - 1) / COLS), (unsigned)((n1 + a.rows_per_block - 1) / a.rows_per_block));
-  const size_t lds = (size_t)prog.nsets * 2 * COLS * sizeof(T);
+  const size_t lds = (size_t)(prog.nsets * 2 + 1) * (COLS + a.rows_per_block) * sizeof(T);
   // 16-byte vector path needs aligned rows
   if (ldk0 % (16 / sizeof(T)) || ldk % (16 / sizeof(T)) || (reinterpret_cast<uintptr_t>(k0) & 15) ||
       (a.out_k && (reinterpret_cast<uintptr_t>(a.out_k) & 15)) || (a.out_t && (reinterpret_cast<uintptr_t>(a.out_t) & 15)))

@@ -6,7 +6,15 @@
 // Dense:  K <- w^2 K + b^2,  Theta <- K_new + w^2 Theta      (NTK parameterisation)
 // act:    (K, Kdot) <- map(K; r_i r_j, s_i s_j),  Theta <- Theta * Kdot      (A.2)
 //
-// One "set" = one activation with its per-row tables (r, s); MLP has L sets, ResNet L + 1.
+// One "set" = one activation with its per-row tables; MLP has L sets, ResNet L + 1.
+//
+// FAST mode (f32, MLP, ReLU, NNGP only — the configuration BASELINE.json is quoted on): the recursion
+// runs in CORRELATION space, which folds each Dense into the table products:
+//     x_0 = K0;   c_l = clamp(x_l * (u^l_i u^l_j) + v^l_i v^l_j);   x_{l+1} = J(c_l);   K = x_L * (sigma_i sigma_j)
+//     u^0 = w r^0, v^l = b r^l, u^l = w s^{l-1} r^l (l >= 1), sigma = last_w s^{L-1},  r = 1/sqrt(q~), s = sqrt(q~/2pi)
+// It is the same arithmetic (c_l is exactly the argument the generic map forms) with 5 ops less per layer
+// and a single-sqrt J (nngp_math.hpp).  The table slots hold (u, v) instead of (r, s) and sigma rides in
+// the NTK-diagonal slot; diag_tables_kernel writes whichever the flag asks for.
 #pragma once
 #include "nngp_math.hpp"
 
@@ -16,11 +24,13 @@ constexpr int kMaxSets = 16;
 
 struct LayerProg {  // plain-old-data kernel argument
   int net, act, nsets;
+  int fast;         // tables are (u, v, sigma): must equal ElemProg<...>::FAST of the kernel launched
   double w2, b2, lw2;
 };
 
 template <typename T, int NET, int ACT, bool NTK>
 struct ElemProg {
+  static constexpr bool FAST = sizeof(T) == 4 && NET == NET_MLP && ACT == ACT_RELU && !NTK;
   T w2, b2, lw2;
   int nsets;
   __device__ __forceinline__ explicit ElemProg(const LayerProg& p)
@@ -38,8 +48,12 @@ struct ElemProg {
       th = T(0);
     }
   }
+  // rr / ss: products of the two per-row table entries of this set (r_i r_j, s_i s_j; FAST: u_i u_j, v_i v_j)
   __device__ __forceinline__ void step(int set, T& k, T& th, T rr, T ss) const {
-    if (NET == NET_MLP) {
+    if constexpr (FAST) {
+      const float c = __builtin_amdgcn_fmed3f(fmaf(k, rr, ss), -1.0f, 1.0f);
+      k = nngp::relu_j_fast(c);
+    } else if (NET == NET_MLP) {
       const T kt = fma(w2, k, b2);
       T tht = T(0);
       if (NTK) tht = fma(w2, th, kt);
@@ -58,8 +72,11 @@ struct ElemProg {
       }
     }
   }
-  __device__ __forceinline__ void post(T& k, T& th) const {
-    if (NET != NET_NONE) {
+  // sig = sigma_i sigma_j (FAST only; ignored otherwise)
+  __device__ __forceinline__ void post(T& k, T& th, T sig) const {
+    if constexpr (FAST) {
+      k *= sig;
+    } else if (NET != NET_NONE) {
       k *= lw2;
       if (NTK) th = fma(lw2, th, k);
     }

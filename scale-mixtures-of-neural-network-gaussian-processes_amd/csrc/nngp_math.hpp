@@ -68,6 +68,24 @@ __device__ __forceinline__ ActOut<T> relu_map(T kt, T rr, T ss) {
   return o;
 }
 
+// J(c) = sqrt(1-c^2) + (pi - acos c) c for the f32 NNGP-only fast path, ONE transcendental:
+//   J(c) = (pi/2)(c + |c|) + (1-|c|)^(3/2) R(|c|),   R(a) = (sqrt(1+a) - a acos(a)/sqrt(1-a)) / (1-a)
+// R is analytic on [0,1]; the degree-5 fit below (minimax-refined least squares) gives |J - exact| <=
+// 3.2e-7 over [-1,1] in f32 arithmetic (1.0e-7 relative to J's range pi; the last ulp of pi is 2.4e-7).
+// J is 1-Lipschitz-ish (J' = pi - acos c <= pi), so this error does not amplify through the layers.
+__device__ __forceinline__ float relu_j_fast(float c) {
+  const float a = fabsf(c);
+  const float d = 1.0f - a;
+  const float s = __builtin_amdgcn_sqrtf(d);
+  float r = -0.0005345707759261131f;
+  r = fmaf(r, a, 0.00260539585724473f);
+  r = fmaf(r, a, -0.007160552311688662f);
+  r = fmaf(r, a, 0.018685804679989815f);
+  r = fmaf(r, a, -0.07078703492879868f);
+  r = fmaf(r, a, 0.9999998807907104f);
+  return fmaf(d * s, r, 1.57079632679489662f * (c + a));
+}
+
 // Erf map.  rr = r_i r_j with r = 1/sqrt(1+2q).
 template <typename T, bool WANT_DOT>
 __device__ __forceinline__ ActOut<T> erf_map(T kt, T rr, T /*ss*/) {
