@@ -75,6 +75,18 @@ def cholesky_launch_model(n_total, n_factor):
     return trail, n_trail, strip, n_strip
 
 
+def pmc_traffic(args, sharded):
+    """Measured HBM-side bytes per launch of the dominant kernel (persistent launches only), from the committed
+    rocprofv3 PMC pass; only valid for the default workload it was taken on."""
+    if sharded or (args.n, args.d, args.layers, args.act, args.dtype) != (16384, 3072, 4, "relu", "f32"):
+        return None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01c_pmc_traffic.json")) as f:
+            return json.load(f)["traffic_bytes_per_launch"]
+    except Exception:
+        return None
+
+
 def cpu_baseline(args, np_dtype, eps):
     """The CPU oracle (NumPy/SciPy port of the same math) on a bounded sample of the workload."""
     import scipy.linalg as sla
@@ -212,7 +224,9 @@ def main():
             "achieved": trail_fl / (trail_ms * 1e-3) / 1e12 if trail_ms > 0 else None,
             "peak": peak, "unit": "TFLOP/s",
             "frac": (trail_fl / (trail_ms * 1e-3) / 1e12 / peak) if trail_ms > 0 else None,
-            "traffic": None,
+            # HBM-side bytes per launch cannot be read without rocprofv3: taken from the committed PMC pass of this
+            # exact workload (profiles/r01c_pmc_traffic.json: FETCH_SIZE x2 + WRITE_SIZE, separate passes), else null
+            "traffic": pmc_traffic(args, sharded),
             "launches_per_step": per["trail"][1], "avg_launch_ms": trail_ms / max(per["trail"][1], 1),
             "flops_per_step": trail_fl,
         }

@@ -47,6 +47,30 @@ __global__ void transpose_kernel(T* __restrict__ dst, int64_t ldd, const T* __re
   }
 }
 
+// L' = J L^T J (J = exchange matrix): dst[i][j] = src[n-1-j][n-1-i], j <= i.  L' is lower triangular and
+// L^T X = B  <=>  L' (J X) = J B, which turns the backward substitution into the forward one.
+template <typename T>
+__global__ void flip_transpose_lower_kernel(T* __restrict__ dst, int64_t ldd, const T* __restrict__ src, int64_t lds,
+                                            int64_t n) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  for (int64_t i = blockIdx.y; i < n; i += gridDim.y)
+    if (j <= i) dst[i * ldd + j] = src[(n - 1 - j) * lds + (n - 1 - i)];
+}
+
+// dst[c][r'] = src[r][c] with r' = flip_dst ? rows-1-r ... (plain, flag-controlled; used only by smn_trsm trans=1)
+template <typename T>
+__global__ void transpose_flip_kernel(T* __restrict__ dst, int64_t ldd, const T* __restrict__ src, int64_t lds,
+                                      int64_t rows, int64_t cols, int flip_src_rows, int flip_dst_rows) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  for (int64_t r = blockIdx.y; r < rows; r += gridDim.y) {
+    const int64_t sr = flip_src_rows ? rows - 1 - r : r;
+    const int64_t dr = flip_dst_rows ? cols - 1 - c : c;
+    dst[dr * ldd + r] = src[sr * lds + c];
+  }
+}
+
 template <typename T>
 __global__ void identity_pad_kernel(T* __restrict__ a, int64_t lda, int64_t n_pad, int64_t n_valid) {
   const int64_t i = n_valid + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -116,6 +140,26 @@ int transpose_matrix(smn_ctx* ctx, int dtype, void* dst, int64_t ldd, const void
   DISPATCH_T(dtype,
              hipLaunchKernelGGL(transpose_kernel<float>, g, b, 0, ctx->stream, static_cast<float*>(dst), ldd, static_cast<const float*>(src), lds, rows, cols),
              hipLaunchKernelGGL(transpose_kernel<double>, g, b, 0, ctx->stream, static_cast<double*>(dst), ldd, static_cast<const double*>(src), lds, rows, cols));
+  SMN_CHECK_LAUNCH(ctx);
+  return SMN_OK;
+}
+
+int flip_transpose_lower(smn_ctx* ctx, int dtype, void* dst, int64_t ldd, const void* src, int64_t lds, int64_t n) {
+  dim3 g((unsigned)((n + 255) / 256), (unsigned)(n < 32768 ? n : 32768));
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(flip_transpose_lower_kernel<float>, g, dim3(256), 0, ctx->stream, static_cast<float*>(dst), ldd, static_cast<const float*>(src), lds, n),
+             hipLaunchKernelGGL(flip_transpose_lower_kernel<double>, g, dim3(256), 0, ctx->stream, static_cast<double*>(dst), ldd, static_cast<const double*>(src), lds, n));
+  SMN_CHECK_LAUNCH(ctx);
+  return SMN_OK;
+}
+
+int transpose_flip(smn_ctx* ctx, int dtype, void* dst, int64_t ldd, const void* src, int64_t lds, int64_t rows,
+                   int64_t cols, int flip_src_rows, int flip_dst_rows) {
+  if (rows <= 0 || cols <= 0) return SMN_OK;
+  dim3 g((unsigned)((cols + 255) / 256), (unsigned)(rows < 32768 ? rows : 32768));
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(transpose_flip_kernel<float>, g, dim3(256), 0, ctx->stream, static_cast<float*>(dst), ldd, static_cast<const float*>(src), lds, rows, cols, flip_src_rows, flip_dst_rows),
+             hipLaunchKernelGGL(transpose_flip_kernel<double>, g, dim3(256), 0, ctx->stream, static_cast<double*>(dst), ldd, static_cast<const double*>(src), lds, rows, cols, flip_src_rows, flip_dst_rows));
   SMN_CHECK_LAUNCH(ctx);
   return SMN_OK;
 }

@@ -144,15 +144,26 @@ extern "C" int smn_trsm(smn_ctx* ctx, int dtype, const void* l_d, int64_t n, int
   if (!ctx || !l_d || !b_d) return SMN_EINVAL;
   if (dtype != SMN_F32 && dtype != SMN_F64) return smn_fail(ctx, SMN_EINVAL, "bad dtype");
   if (n <= 0 || nrhs <= 0) return smn_fail(ctx, SMN_EINVAL, "smn_trsm: empty");
-  if (trans != 0) return smn_fail(ctx, SMN_ENOTSUP, "smn_trsm: trans=1 (L^T) is not implemented yet");
+  if (trans != 0 && trans != 1) return smn_fail(ctx, SMN_EINVAL, "smn_trsm: trans must be 0 or 1");
+  // X = L^-1 B  <=>  X^T = B^T L^-T: the columns of B ride through the panel sweep as appended rows.
+  // trans = 1: L^T X = B  <=>  L' (J X) = J B with L' = J L^T J lower triangular (J reverses the order),
+  // so the same forward sweep serves the backward substitution.
   Aug g;
   SMN_TRY(aug_alloc(ctx, dtype, n, nrhs, 0, &g));
   SMN_HIP(ctx, hipMemsetAsync(g.a, 0, g.es * (size_t)g.n_total * (size_t)g.n_total, ctx->stream));
-  SMN_TRY(copy_matrix(ctx, dtype, g.a, g.lda, l_d, ldl, n, n, 1));
+  if (trans == 0) {
+    SMN_TRY(copy_matrix(ctx, dtype, g.a, g.lda, l_d, ldl, n, n, 1));
+    SMN_TRY(transpose_matrix(ctx, dtype, g.at(g.n_pad, 0), g.lda, b_d, ldb, n, nrhs));
+  } else {
+    SMN_TRY(flip_transpose_lower(ctx, dtype, g.a, g.lda, l_d, ldl, n));
+    SMN_TRY(transpose_flip(ctx, dtype, g.at(g.n_pad, 0), g.lda, b_d, ldb, n, nrhs, 1, 0));
+  }
   SMN_TRY(fill_identity_pad(ctx, dtype, g.a, g.lda, g.n_pad, n));
-  SMN_TRY(transpose_matrix(ctx, dtype, g.at(g.n_pad, 0), g.lda, b_d, ldb, n, nrhs));
   SMN_TRY(solve_rows_padded(ctx, dtype, g.a, g.n_total, g.n_pad, g.lda));
-  SMN_TRY(transpose_matrix(ctx, dtype, b_d, ldb, g.at(g.n_pad, 0), g.lda, nrhs, n));
+  if (trans == 0)
+    SMN_TRY(transpose_matrix(ctx, dtype, b_d, ldb, g.at(g.n_pad, 0), g.lda, nrhs, n));
+  else
+    SMN_TRY(transpose_flip(ctx, dtype, b_d, ldb, g.at(g.n_pad, 0), g.lda, nrhs, n, 0, 1));
   return SMN_OK;
 }
 

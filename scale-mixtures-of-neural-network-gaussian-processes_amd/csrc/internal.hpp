@@ -56,3 +56,7 @@ int extract_posterior(smn_ctx* ctx, int dtype, const void* a, int64_t lda, int64
 int solve_rows_padded(smn_ctx* ctx, int dtype, void* a, int64_t n_total, int64_t n_factor, int64_t lda);
 int transpose_matrix(smn_ctx* ctx, int dtype, void* dst, int64_t ldd, const void* src, int64_t lds,
                      int64_t rows, int64_t cols);   // dst[c, r] = src[r, c]
+// dst[i, j] = src[n-1-j, n-1-i] for j <= i  (J L^T J);  transpose with the src rows / dst rows reversed
+int flip_transpose_lower(smn_ctx* ctx, int dtype, void* dst, int64_t ldd, const void* src, int64_t lds, int64_t n);
+int transpose_flip(smn_ctx* ctx, int dtype, void* dst, int64_t ldd, const void* src, int64_t lds, int64_t rows,
+                   int64_t cols, int flip_src_rows, int flip_dst_rows);

@@ -1,0 +1,108 @@
+"""Batched hyper-parameter sweeps on one dataset — the grid search of experiments/regression/find.py:134-199
+restructured around what can be reused on the device:
+
+  * the input Gram K0 = [X; X*][X; X*]^T / d is built ONCE (smn_gram);
+  * each (w_std, b_std) only re-runs the elementwise layer recursion on it (smn_recursion, HBM-streaming);
+  * each eps costs two factorizations of that kernel (the reference does the same two: find.py:141 predict
+    with neural_tangents' relative ridge, find.py:151-159 inv / logdet with the absolute eps);
+  * every (alpha, beta) of the Burr-XII scale mixture is host arithmetic on the scalars and T-vectors that
+    came back (find.py:165-187, reproduced as written, including prob_prior == prob_q and random_state=101).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _lib
+from ._lib import as_device, default_context
+
+__all__ = ["find_grid"]
+
+_NET = {"mlp": _lib.NET_MLP, None: _lib.NET_MLP, "resnet": _lib.NET_DENSE_RESNET}
+
+
+def _norm_logpdf(x, mean, sigma):
+    z = (x - mean) / sigma
+    return -0.5 * z * z - np.log(sigma) - 0.5 * math.log(2 * math.pi)
+
+
+def find_grid(x_train, y_train, x_test, y_test, y_mean=0.0, y_std=1.0, *, network="mlp", num_hiddens=4,
+              activation="relu", w_std_list=(1.0, 1.4, 2.0), b_std_list=(0.0, 0.3, 1.0),
+              eps_list=(1e-6, 1e-4, 1e-2), alpha_list=(1.0, 2.0, 3.0), beta_list=(1.0, 2.0, 3.0),
+              num_samples=1000, ctx=None):
+    """Returns dict(gnll[i,j,k], tnll[i,j,k,a,b], best_gaussian, best_student) — the tables find.py logs."""
+    from scipy import stats as scipy_stats       # host-only, same dependency as the reference's find.py
+    from scipy.special import logsumexp
+
+    if network not in _NET:
+        raise ValueError(f"Unsupported network '{network}'")
+    act = _lib.ACT[activation] if activation in _lib.ACT else None
+    if act is None:
+        raise KeyError("Unsupported act '{}'".format(activation))
+    ctx = ctx or default_context()
+    xt = as_device(x_train, ctx)
+    dt = xt.dtype
+    n, d = xt.shape
+    xs = np.asarray(x_test, dtype=dt)
+    t = xs.shape[0]
+    xa = ctx.to_device(np.concatenate([np.asarray(x_train, dtype=dt), xs], axis=0))
+    y = np.asarray(y_train, dtype=np.float64).reshape(-1)
+    yd = ctx.to_device(y.astype(dt).reshape(n, 1))
+    code = xa.dcode
+    m = n + t
+    ldm = (m + 3) // 4 * 4                     # 16-byte aligned rows for the streaming recursion kernel
+    k0 = ctx.empty((m, ldm), dt)
+    q = ctx.empty((m,), dt)
+    ctx.call("smn_gram", code, xa.ptr, m, d, None, 0, 0, d, k0.ptr, ldm, q.ptr, None)     # once per dataset
+    kj = ctx.empty((m, ldm), dt)
+    mean_d = ctx.empty((t, 1), dt)
+    cov_d = ctx.empty((t, t), dt)
+    y_ = np.asarray(y_test, dtype=np.float64) * y_std + y_mean
+    minus_log_two_pi = -(n / 2) * math.log(2 * math.pi)
+    gnll = np.full((len(w_std_list), len(b_std_list), len(eps_list)), np.nan)
+    tnll = np.full(gnll.shape + (len(alpha_list), len(beta_list)), np.nan)
+    quad, logdet, info = C.c_double(), C.c_double(), C.c_int()
+    for i, w in enumerate(w_std_list):
+        for j, b in enumerate(b_std_list):
+            ctx.call("smn_recursion", code, _NET[network], act, num_hiddens, float(w), float(b), 1.0, k0.ptr, m, m, ldm,
+                     q.ptr, q.ptr, 1, _lib.GET_NNGP, kj.ptr, None, ldm)                       # once per (w, b)
+            for k, eps in enumerate(eps_list):
+                ctx.call("smn_predict", code, kj.ptr, n, t, ldm, yd.ptr, 1, float(eps), 0.0, mean_d.ptr, cov_d.ptr, t,
+                         None, None, C.byref(info))
+                if info.value:
+                    continue
+                mean_ = mean_d.numpy().astype(np.float64).ravel() * y_std + y_mean
+                cov = cov_d.numpy().astype(np.float64)
+                std_diag = np.sqrt(np.diag(cov))
+                gnll[i, j, k] = -np.mean(_norm_logpdf(y_, mean_, std_diag * y_std))         # find.py:50-55,145
+                # find.py:151-159 — y^T (K + eps I)^-1 y and log det, absolute eps, training block of kj
+                ctx.call("smn_lml", code, kj.ptr, n, ldm, yd.ptr, float(eps), 0.0, 1.0, None, C.byref(quad),
+                         C.byref(logdet), C.byref(info))
+                if info.value:
+                    continue
+                minus_quad = -0.5 * quad.value
+                minus_log_det = -0.5 * logdet.value
+                for ia, a in enumerate(alpha_list):
+                    for ib, bb in enumerate(beta_list):
+                        sample_q = scipy_stats.burr12.rvs(c=a, d=bb, loc=0., scale=1., size=num_samples, random_state=101)
+                        minus_log_sigma = -(1 / 2) * n * np.log(sample_q)
+                        prob_prior = scipy_stats.burr12.pdf(sample_q, c=a, d=bb, loc=0., scale=1.)
+                        prob_q = prob_prior
+                        log_prob_data = minus_log_two_pi + minus_log_det + minus_quad / sample_q + minus_log_sigma
+                        prob_data = np.exp(log_prob_data - log_prob_data.max())
+                        wgt = prob_data * prob_prior / prob_q
+                        w_bar = wgt / np.sum(wgt)
+                        std = np.sqrt(sample_q[:, None]) * std_diag[None, :]
+                        log_probs = np.log(w_bar + 1e-24)[:, None] + _norm_logpdf(y_, mean_, std * y_std)
+                        tnll[i, j, k, ia, ib] = -np.mean(logsumexp(log_probs, axis=0))
+    out = dict(gnll=gnll, tnll=tnll, best_gaussian=None, best_student=None)
+    if np.isfinite(gnll).any():
+        i, j, k = np.unravel_index(np.nanargmin(gnll), gnll.shape)
+        out["best_gaussian"] = ((w_std_list[i], b_std_list[j], eps_list[k]), float(gnll[i, j, k]))
+    if np.isfinite(tnll).any():
+        i, j, k, ia, ib = np.unravel_index(np.nanargmin(tnll), tnll.shape)
+        out["best_student"] = ((w_std_list[i], b_std_list[j], alpha_list[ia], beta_list[ib], eps_list[k]),
+                               float(tnll[i, j, k, ia, ib]))
+    return out

@@ -1,0 +1,74 @@
+"""Training step for SPR — the counterpart of experiments/regression/train.py:61-67
+(`objax.GradValues(model.loss, vars)` + `objax.optimizer.Adam`) without autodiff.
+
+The model has at most six trainable scalars (w_std, b_std, last_w_std, eps and, for the Student-t
+likelihood, a, b — the names experiments/regression/test.py:38-43 matches checkpoints by), all stored
+as softplus-inverse raw values (spax/base.py:15-25).  The gradient of the loss with respect to those raw
+values is taken by central differences: 2 loss evaluations (= 2 fused build + Cholesky passes on the GPU)
+per variable.  This is SURVEY.md section 8f.1's finite-difference fallback; the analytic form
+(1/2 tr((aa^T - K^-1) dK/dtheta) with forward-mode dK/dtheta through the fused recursion) is not built yet.
+Use float64 data: in float32 the loss carries ~1e-6 relative noise and the quotient is dominated by it.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+from .spax.base import TrainVar
+
+__all__ = ["train_vars", "value_and_grad_fd", "Adam", "build_train_step"]
+
+
+def train_vars(model):
+    """Dotted-name -> TrainVar for every trainable of the model (kernel, likelihood, eps)."""
+    return {k: v for k, v in model.vars().items() if isinstance(v, TrainVar)}
+
+
+def value_and_grad_fd(loss_fn, variables, h=1e-4):
+    """(loss, {name: dloss/draw}) by central differences on the raw (unconstrained) values."""
+    value = float(loss_fn())
+    grads = {}
+    for name, var in variables.items():
+        raw = float(var.value)
+        step = h * max(1.0, abs(raw))
+        var.assign(raw + step)
+        up = float(loss_fn())
+        var.assign(raw - step)
+        dn = float(loss_fn())
+        var.assign(raw)
+        grads[name] = (up - dn) / (2.0 * step)
+    return value, grads
+
+
+class Adam:
+    """objax.optimizer.Adam defaults (beta1=0.9, beta2=0.999, eps=1e-8), called as optimizer(lr, grads)."""
+
+    def __init__(self, variables, beta1=0.9, beta2=0.999, eps=1e-8):
+        self.vars, self.b1, self.b2, self.eps = variables, beta1, beta2, eps
+        self.m = {k: 0.0 for k in variables}
+        self.v = {k: 0.0 for k in variables}
+        self.t = 0
+
+    def __call__(self, lr, grads):
+        self.t += 1
+        lr_t = lr * math.sqrt(1 - self.b2 ** self.t) / (1 - self.b1 ** self.t)
+        for k, g in grads.items():
+            if not np.isfinite(g):
+                continue
+            self.m[k] = self.b1 * self.m[k] + (1 - self.b1) * g
+            self.v[k] = self.b2 * self.v[k] + (1 - self.b2) * g * g
+            self.vars[k].assign(float(self.vars[k].value) - lr_t * self.m[k] / (math.sqrt(self.v[k]) + self.eps))
+
+
+def build_train_step(model, variables=None, optimizer=None, h=1e-4):
+    """train_step(learning_rate) -> loss before the update  (regression/train.py:61-67)."""
+    variables = variables if variables is not None else train_vars(model)
+    optimizer = optimizer or Adam(variables)
+
+    def train_step(learning_rate):
+        value, grads = value_and_grad_fd(model.loss, variables, h=h)
+        optimizer(learning_rate, grads)
+        return value
+
+    return train_step

@@ -235,6 +235,11 @@ def test_trsm_lower(L, ctx, dtype):
     ctx.call("smn_trsm", L.dtype_code(dtype), ld.ptr, n, n, bd.ptr, r, r, 0)
     ref = sla.solve_triangular(l, b, lower=True)
     assert relerr(bd.numpy(), ref) < (1e-9 if dtype == np.float64 else 2e-3)
+    # trans = 1: L^T X = B; together the two solves are cho_solve (K^-1 B)
+    ctx.call("smn_trsm", L.dtype_code(dtype), ld.ptr, n, n, bd.ptr, r, r, 1)
+    ref2 = sla.solve_triangular(l, ref, lower=True, trans="T")
+    assert relerr(bd.numpy(), ref2) < (1e-8 if dtype == np.float64 else 5e-3)
+    assert relerr(bd.numpy(), sla.cho_solve((l, True), b)) < (1e-8 if dtype == np.float64 else 5e-3)
 
 
 # ----------------------------------------------------------------------------- heads
@@ -347,3 +352,74 @@ def test_not_pd_gives_nan_like_the_reference():
     k = NNGPKernel(lambda w, b, l: nt_kernels.get_mlp_kernel(1, act="relu", w_std=w, b_std=b, last_w_std=l), 1., 1e-8, 1.)
     m = SPR(k, GaussianLikelihood(), x.astype(np.float32), y.astype(np.float32), 0.0, 1.0, eps=1e-12)
     assert np.isnan(m.loss())
+
+
+# ----------------------------------------------------------------------------- "next" rows
+def test_find_grid_matches_reference_formulas():
+    """experiments/regression/find.py:134-199 with K0 reused across (w,b): every table entry vs the same
+    formulas evaluated with the CPU oracle."""
+    from scipy import stats as sst
+    from scipy.special import logsumexp
+    from smnngp import sweeps
+    rng = np.random.default_rng(21)
+    n, t, d = 61, 9, 4
+    x = rng.standard_normal((n, d)); y = rng.standard_normal(n)
+    xt = rng.standard_normal((t, d)); yt = rng.standard_normal(t)
+    ws, bs, es, als, bes = (1.0, 1.4), (0.0, 0.3), (1e-4, 1e-2), (1.0, 2.0), (1.0, 3.0)
+    got = sweeps.find_grid(x, y, xt, yt, 0.2, 1.3, network="mlp", num_hiddens=2, activation="relu", w_std_list=ws,
+                           b_std_list=bs, eps_list=es, alpha_list=als, beta_list=bes)
+    y_ = yt * 1.3 + 0.2
+    for i, w in enumerate(ws):
+        for j, b in enumerate(bs):
+            kw = dict(num_hiddens=2, act="relu", w_std=w, b_std=b, last_w_std=1.0)
+            kdd = O.mlp_kernel(x, None, **kw); ktd = O.mlp_kernel(xt, x, **kw); ktt = O.mlp_kernel(xt, None, **kw)
+            for k, eps in enumerate(es):
+                mean, cov = O.predict(kdd, ktd, ktt, y[:, None], diag_reg=eps)
+                mean_ = mean.ravel() * 1.3 + 0.2
+                sd = np.sqrt(np.diag(cov))
+                g = -np.mean(O.normal_logpdf(y_, mean_, sd * 1.3))
+                assert abs(got["gnll"][i, j, k] - g) < 1e-6 * max(1, abs(g))
+                ke = kdd + eps * np.eye(n)
+                quad = y @ np.linalg.solve(ke, y); logdet = np.linalg.slogdet(ke)[1]
+                for ia, a in enumerate(als):
+                    for ib, be in enumerate(bes):
+                        sq = sst.burr12.rvs(c=a, d=be, loc=0., scale=1., size=1000, random_state=101)
+                        lpd = -(n / 2) * np.log(2 * np.pi) - 0.5 * logdet - 0.5 * quad / sq - 0.5 * n * np.log(sq)
+                        wgt = np.exp(lpd - lpd.max()); wb = wgt / wgt.sum()
+                        lps = np.log(wb + 1e-24)[:, None] + O.normal_logpdf(y_, mean_, np.sqrt(sq[:, None]) * sd[None, :] * 1.3)
+                        tn = -np.mean(logsumexp(lps, axis=0))
+                        assert abs(got["tnll"][i, j, k, ia, ib] - tn) < 1e-6 * max(1, abs(tn)), (w, b, eps, a, be)
+    assert got["best_gaussian"] is not None and got["best_student"] is not None
+
+
+def test_finite_difference_train_step():
+    """regression/train.py:61-67 (GradValues + Adam) on the facade: the FD gradient equals the FD gradient of the
+    oracle loss, and a few Adam steps lower the loss."""
+    from smnngp import nt_kernels, train
+    from smnngp.spax.kernels import NNGPKernel
+    from smnngp.spax.likelihoods import StudentTLikelihood
+    from smnngp.spax.models import SPR
+    rng = np.random.default_rng(31)
+    n, d = 80, 3
+    x = rng.standard_normal((n, d)); y = np.sin(x[:, 0]) + 0.1 * rng.standard_normal(n)
+    kernel = NNGPKernel(lambda w, b, l: nt_kernels.get_mlp_kernel(2, act="relu", w_std=w, b_std=b, last_w_std=l), 1.0, 0.5, 1.0)
+    lik = StudentTLikelihood(2.0, 2.0)
+    model = SPR(kernel, lik, x, y, 0.0, 1.0, eps=1e-2)
+    tv = train.train_vars(model)
+    assert sorted(k.split(".")[-1] for k in tv) == ["a", "b", "b_std", "eps", "last_w_std", "w_std"]
+    val, grads = train.value_and_grad_fd(model.loss, tv, h=1e-5)
+
+    def oracle_loss(raw):
+        p = {k.split(".")[-1]: float(O.softplus(v)) for k, v in raw.items()}
+        return O.spr_loss(x, y, num_hiddens=2, act="relu", w_std=p["w_std"], b_std=p["b_std"], last_w_std=p["last_w_std"],
+                          eps=p["eps"], method="tp", alpha=p["a"], beta=p["b"])
+    raw0 = {k: float(v.value) for k, v in tv.items()}
+    assert abs(val - oracle_loss(raw0)) < 1e-9
+    for k in tv:
+        hh = 1e-5 * max(1.0, abs(raw0[k]))
+        up = dict(raw0); up[k] += hh; dn = dict(raw0); dn[k] -= hh
+        ref = (oracle_loss(up) - oracle_loss(dn)) / (2 * hh)
+        assert abs(grads[k] - ref) < 1e-5 * max(1.0, abs(ref)), (k, grads[k], ref)
+    step = train.build_train_step(model)
+    losses = [step(1e-2) for _ in range(12)]
+    assert model.loss() < losses[0] - 1e-4 and all(np.isfinite(losses))
