@@ -52,6 +52,32 @@ def cholesky_launch_model(n_total, n_factor):
     trail = strip = 0.0
     n_trail = n_strip = 0
     W = 2 * TILE
+    la = os.environ.get("SMN_LOOKAHEAD", "0") == "1"
+    S = int(os.environ.get("SMN_SUPER", "1024")) // W * W
+    if not la and S > W:                     # two-level schedule: near trapezoids (K=256) + far updates (K=S)
+        s0 = 0
+        while s0 < n_factor:
+            s_end = n_factor if n_factor - s0 < S else s0 + S
+            j0 = s0
+            while j0 < s_end:
+                w = min(W, s_end - j0)
+                js = j0 + TILE
+                while js < j0 + w:
+                    strip += ((n_total - js) // TILE) * TILE * TILE * 2.0 * (js - j0)
+                    n_strip += 1
+                    js += TILE
+                j1 = j0 + w
+                if j1 < s_end:
+                    tm, tn = (n_total - j1) // TILE, (s_end - j1) // TILE
+                    trail += (tn * (tn + 1) // 2 + (tm - tn) * tn) * TILE * TILE * 2.0 * w
+                    n_trail += 1
+                j0 += W
+            if s_end < n_total:
+                t = (n_total - s_end) // TILE
+                trail += (t * (t + 1) // 2) * TILE * TILE * 2.0 * (s_end - s0)
+                n_trail += 1
+            s0 += S
+        return trail, n_trail, strip, n_strip
     j0 = 0
     while j0 < n_factor:
         w = min(W, n_factor - j0)
@@ -81,7 +107,7 @@ def pmc_traffic(args, sharded):
     if sharded or (args.n, args.d, args.layers, args.act, args.dtype) != (16384, 3072, 4, "relu", "f32"):
         return None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01c_pmc_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r01d_pmc_traffic.json")) as f:
             return json.load(f)["traffic_bytes_per_launch"]
     except Exception:
         return None
@@ -217,15 +243,16 @@ def main():
             build_fl = ((n // world + TILE - 1) // TILE) * (n // TILE) * TILE * TILE * 2.0 * kp
         trail_ms = per["trail"][0]
         roof = {
-            "kernel": ("trail_kernel<float> (persistent) + update_kernel<float,1> (launches under 512 tiles)"
+            "kernel": ("update_kernel<float,1> + trail_kernel<float> (persistent form, launches over 512 tiles)"
                        if args.dtype == "f32" else "update_kernel<double,1>")
-                      + ": Cholesky trailing update C -= P P^T, K=256, lower 128x128 tiles",
+                      + ": Cholesky trailing update C -= P P^T on lower 128x128 tiles (two-level: K=256 inside a "
+                        "super-panel, K=super-panel width beyond it)",
             "bound": "mfma",
             "achieved": trail_fl / (trail_ms * 1e-3) / 1e12 if trail_ms > 0 else None,
             "peak": peak, "unit": "TFLOP/s",
             "frac": (trail_fl / (trail_ms * 1e-3) / 1e12 / peak) if trail_ms > 0 else None,
             # HBM-side bytes per launch cannot be read without rocprofv3: taken from the committed PMC pass of this
-            # exact workload (profiles/r01c_pmc_traffic.json: FETCH_SIZE x2 + WRITE_SIZE, separate passes), else null
+            # exact workload (profiles/r01d_pmc_traffic.json: FETCH_SIZE x2 + WRITE_SIZE, separate passes), else null
             "traffic": pmc_traffic(args, sharded),
             "launches_per_step": per["trail"][1], "avg_launch_ms": trail_ms / max(per["trail"][1], 1),
             "flops_per_step": trail_fl,

@@ -241,12 +241,32 @@ __global__ void copy_diag_kernel(T* __restrict__ a, int64_t lda, const T* __rest
 
 // C[r0 + ., c0 + .] -= A_rows * B_rows^T over K columns starting at column k0 of the same matrix.
 //   A_rows = a[r0 + tile_r*128 ..., k0 : k0+K],  B_rows = a[c0 + tile_c*128 ..., k0 : k0+K]
-// lower != 0: triangular tile enumeration (tc <= tr), requires r0 == c0.
+// lower: 0 = rectangle tiles_m x tiles_n; 1 = lower triangle (tc <= tr, tiles_m == tiles_n, r0 == c0);
+//        2 = lower trapezoid: tiles_n tile columns, all rows from the diagonal down (triangle first, then
+//            the rectangle under it), r0 == c0.
 template <typename T>
 struct UpdArgs {
   T* a; int64_t lda; int64_t r0, c0, k0; int K; int tiles_n; int lower;
   int use_map; TileMap map;   // XCD-aware patch order (gemm_nt.hpp) instead of the linear one
 };
+
+template <typename T>
+__device__ __forceinline__ void upd_decode(const UpdArgs<T>& u, int tl, int& tr, int& tc) {
+  if (u.lower == 1) {
+    tri_decode(tl, tr, tc);
+  } else if (u.lower == 2) {
+    const int ntri = u.tiles_n * (u.tiles_n + 1) / 2;
+    if (tl < ntri) {
+      tri_decode(tl, tr, tc);
+    } else {
+      tr = u.tiles_n + (tl - ntri) / u.tiles_n;
+      tc = (tl - ntri) % u.tiles_n;
+    }
+  } else {
+    tr = tl / u.tiles_n;
+    tc = tl % u.tiles_n;
+  }
+}
 
 // TAG only separates the two uses into two symbols (0: strip update, 1: trailing update) so that
 // rocprofv3 --stats reports them on separate lines.
@@ -258,11 +278,8 @@ __global__ void __launch_bounds__(256, sizeof(T) == 8 ? 1 : 2) update_kernel(Upd
   int tr, tc;
   if (u.use_map) {
     if (!u.map.decode(blockIdx.x, tr, tc)) return;   // padding slot of a patch (uniform per workgroup)
-  } else if (u.lower) {
-    tri_decode(blockIdx.x, tr, tc);
   } else {
-    tr = blockIdx.x / u.tiles_n;
-    tc = blockIdx.x % u.tiles_n;
+    upd_decode(u, (int)blockIdx.x, tr, tc);
   }
   const int64_t row0 = u.r0 + (int64_t)tr * kTile, col0 = u.c0 + (int64_t)tc * kTile;
   Tile t;
@@ -319,7 +336,7 @@ __global__ void __launch_bounds__(256, 2) trail_kernel(UpdArgs<T> u, int ntiles)
 
   auto origin = [&](int tl, int64_t& row0, int64_t& col0) {
     int tr, tc;
-    tri_decode(tl, tr, tc);
+    upd_decode(u, tl, tr, tc);
     row0 = u.r0 + (int64_t)tr * kTile;
     col0 = u.c0 + (int64_t)tc * kTile;
   };
@@ -431,16 +448,22 @@ template <typename T>
 int launch_update(smn_ctx* ctx, hipStream_t st, T* a, int64_t lda, int64_t r0, int64_t c0, int64_t k0, int K,
                   int64_t tiles_m, int64_t tiles_n, int lower, int tag = -1) {
   if (tiles_m <= 0 || tiles_n <= 0 || K <= 0) return SMN_OK;
-  if (tag < 0) tag = lower;   // 0: strip update, 1: trailing update (separate symbols / profile categories)
-  UpdArgs<T> u{a, lda, r0, c0, k0, K, (int)tiles_n, lower, 0, TileMap::make(tiles_m, tiles_n, lower)};
-  int64_t nt = lower ? tiles_m * (tiles_m + 1) / 2 : tiles_m * tiles_n;
-  if (ctx->xcd_map && nt >= 512) {   // small launches do not fill the XCDs anyway
+  if (tag < 0) tag = lower ? 1 : 0;   // 0: strip update, 1: trailing update (separate symbols / profile categories)
+  if (lower == 2 && tiles_n >= tiles_m) {   // a trapezoid as wide as it is tall is the triangle
+    lower = 1;
+    tiles_n = tiles_m;
+  }
+  UpdArgs<T> u{a, lda, r0, c0, k0, K, (int)tiles_n, lower, 0, TileMap::make(tiles_m, tiles_n, lower == 1)};
+  int64_t nt = lower == 1   ? tiles_m * (tiles_m + 1) / 2
+               : lower == 2 ? tiles_n * (tiles_n + 1) / 2 + (tiles_m - tiles_n) * tiles_n
+                            : tiles_m * tiles_n;
+  if (ctx->xcd_map && nt >= 512 && lower != 2) {   // small launches do not fill the XCDs anyway
     u.use_map = 1;
     nt = u.map.grid;
   }
   const size_t lds = MainTile<T>::LDS_BYTES;
   if constexpr (sizeof(T) == 4) {
-    if (tag == 1 && lower && !u.use_map && ctx->persistent_trail && nt > 2 * ctx->num_cu) {
+    if (tag == 1 && lower && !u.use_map && ctx->persistent_trail && nt > 2 * ctx->num_cu && K <= 512) {
       // persistent walk over the lower tiles, two workgroups per CU
       const size_t plds = TileNT<T, kTile, kTile, 2>::LDS_BYTES;
       ProfScope ps(ctx, PROF_TRAIL, st);
@@ -523,6 +546,38 @@ int cholesky_t(smn_ctx* ctx, T* a, int64_t n_total, int64_t n_factor, int64_t ld
   // cannot share a CU with the two resident update workgroups, so today the chain just queues.
   constexpr int64_t W = 2 * PB;
   const bool la = ctx->lookahead;
+  // Two-level schedule (default): inside a super-panel of S columns the K = 256 updates touch only the
+  // super-panel's own columns (a lower trapezoid); everything to the right of it is brought up to date ONCE,
+  // when the super-panel is finished, with K = S.  Same flops, but most of them now run at long K, where the
+  // tile engine is ~25 % faster (profiles/r01b_gemm_probe.txt) and the C block is read and written once per S
+  // columns instead of once per 256.
+  const int64_t S = ctx->super_panel / W * W;
+  if (!la && S > W) {
+    for (int64_t s0 = 0; s0 < n_factor; s0 += S) {
+      const int64_t s_end = (n_factor - s0 < S) ? n_factor : s0 + S;
+      for (int64_t j0 = s0; j0 < s_end; j0 += W) {
+        const int64_t w = (s_end - j0 < W) ? s_end - j0 : W;
+        for (int64_t js = j0; js < j0 + w; js += PB) {
+          if (js > j0)
+            SMN_TRY(launch_update<T>(ctx, st, a, lda, js, js, j0, (int)(js - j0), (n_total - js) / kTile, 1, 0));
+          SMN_TRY(launch_panel<T>(ctx, st, a, lda, js, n_total, 0));
+        }
+        const int64_t j1 = j0 + w;
+        if (j1 < s_end)   // near update: columns [j1, s_end), all rows from the diagonal down
+          SMN_TRY(launch_update<T>(ctx, st, a, lda, j1, j1, j0, (int)w, (n_total - j1) / kTile, (s_end - j1) / kTile, 2));
+      }
+      if (s_end < n_total) {   // far update: K = s_end - s0
+        const int64_t tm = (n_total - s_end) / kTile;
+        SMN_TRY(launch_update<T>(ctx, st, a, lda, s_end, s_end, s0, (int)(s_end - s0), tm, tm, 1));
+      }
+    }
+    if (keep_factor) {
+      hipLaunchKernelGGL(copy_diag_kernel<T>, dim3((unsigned)(n_factor / PB)), dim3(1024), 0, st, a, lda,
+                         static_cast<const T*>(side));
+      SMN_CHECK_LAUNCH(ctx);
+    }
+    return SMN_OK;
+  }
   hipStream_t s2 = la ? ctx->stream2 : st;
   if (la) {
     SMN_HIP(ctx, hipEventRecord(ctx->ev_a, st));
