@@ -5,7 +5,8 @@ One "step" = one SPR.loss evaluation (spax/models.py:93-98) on synthetic inputs 
 fused Gram + 4-layer ReLU recursion -> K + eps I -> blocked Cholesky with y carried -> log-marginal
 likelihood.  Workload at N=1: BASELINE.json configs[3] shape on one GPU (N=16384, d=3072, L=4, fp32).
 With --gpus P > 1 (launched by torch.distributed.run, one rank per GPU): the kernel build is row-sharded
-over the ranks, assembled with ONE RCCL all-gather, and every rank factors the assembled kernel
+over the ranks (paired lower-block layout, sharding.py), assembled with ONE RCCL all-gather, and every rank
+factors the assembled kernel
 (strong scaling: total work fixed).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
@@ -175,6 +176,10 @@ def main():
         dist.broadcast(t, 0)
         uid = C.create_string_buffer(bytes(t.tolist()), 128)
         ctx.call("smn_comm_init", world, rank, uid)
+    elif args.sharded_path:                        # 1-GPU rehearsal of the N>1 path: a real one-rank RCCL communicator
+        uid = C.create_string_buffer(128)
+        assert L._lib.smn_comm_unique_id(uid) == 0, "RCCL unavailable"
+        ctx.call("smn_comm_init", 1, 0, uid)
 
     rng = np.random.default_rng(0)                 # same seed on every rank: X is replicated
     x = ctx.to_device(rng.standard_normal((n, d)).astype(np_dtype))
@@ -187,18 +192,17 @@ def main():
             ctx.call("smn_spr_loss", code, L.NET_MLP, act, nl, 1.0, 1e-8, 1.0, x.ptr, n, d, d, y.ptr, eps, 0.0, 1.0,
                      C.byref(lp), C.byref(quad), C.byref(logdet), C.byref(info))
     else:
+        # Balanced symmetric shard (sharding.py, paired layout): rank r builds the lower trapezoids of row blocks
+        # r and 2P-1-r packed into its chunk of `stage`, ONE in-place RCCL all-gather moves N^2/2-ish elements in
+        # total, an unpack kernel scatters them into K's lower triangle, and smn_lml (replicated) reads only that.
         from smnngp import sharding
-        rows = sharding.rows_per_rank(n, world)
-        rb, re = sharding.row_shard(n, world, rank)
-        kfull = ctx.empty((sharding.gathered_rows(n, world), n), np_dtype)   # rows >= n are gather padding
         es = np.dtype(np_dtype).itemsize
-        mine = C.c_void_p(kfull.ptr.value + rank * rows * n * es)
+        stage = ctx.empty((world * sharding.paired_chunk_elems(n, world),), np_dtype)
+        kfull = ctx.empty((n, n), np_dtype)
 
         def step():
-            if re > rb:
-                ctx.call("smn_kernel_mlp_rows", code, L.NET_MLP, act, nl, 1.0, 1e-8, 1.0, x.ptr, n, d, d,
-                         rb, re, L.GET_NNGP, mine, None, n)
-            ctx.call("smn_allgather", code, mine, kfull.ptr, sharding.chunk_elems(n, world, n))   # in place
+            sharding.build_lower_sharded(ctx, code, es, L.NET_MLP, act, nl, 1.0, 1e-8, 1.0, x.ptr, n, d, d,
+                                         rank, world, stage.ptr, kfull.ptr, n)
             ctx.call("smn_lml", code, kfull.ptr, n, n, y.ptr, eps, 0.0, 1.0, C.byref(lp), C.byref(quad),
                      C.byref(logdet), C.byref(info))
 
@@ -240,7 +244,12 @@ def main():
             t = n_total // TILE
             build_fl = (t * (t + 1) // 2) * TILE * TILE * 2.0 * kp
         else:
-            build_fl = ((n // world + TILE - 1) // TILE) * (n // TILE) * TILE * TILE * 2.0 * kp
+            from smnngp import sharding as S_
+            tiles = 0                                                     # lower tiles rank 0's two blocks execute
+            for b in S_.paired_blocks(world, 0):
+                rb_, re_ = S_.block_range(n, world, b)
+                tiles += sum(t + 1 for t in range(rb_ // TILE, -(-re_ // TILE)))
+            build_fl = tiles * TILE * TILE * 2.0 * kp
         trail_ms = per["trail"][0]
         roof = {
             "kernel": ("update_kernel<float,1> + trail_kernel<float> (persistent form, launches over 512 tiles)"
@@ -272,7 +281,7 @@ def main():
                                    % (n, d, nl, args.act),
                        "N": n, "d": d, "layers": nl, "act": args.act, "w_std": 1.0, "b_std": 1e-8, "last_w_std": 1.0,
                        "eps_abs": eps, "flops_counted": flops_counted,
-                       "parallelism": "single GPU" if not sharded else "row-sharded build x%d + RCCL all-gather + replicated Cholesky" % world},
+                       "parallelism": "single GPU" if not sharded else "paired lower-block row shards x%d + one RCCL all-gather + replicated Cholesky" % world},
             "phases_ms": {k: round(v[0], 4) for k, v in per.items()},
             "result": {"logpdf": lp.value, "logdet": logdet.value, "info": info.value},
             "roofline": roof,

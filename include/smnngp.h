@@ -88,6 +88,26 @@ int smn_kernel_mlp_rows(smn_ctx* ctx, int dtype, int net, int act, int num_hidde
                         int64_t row_begin, int64_t row_end, int get_mask,
                         void* nngp_rows_d, void* ntk_rows_d, int64_t ldk);
 
+/* Balanced symmetric shard: rows [row_begin,row_end) x columns [0,row_end) only (the lower
+ * trapezoid of that row block; 128x128 tiles wholly above the diagonal are skipped and what lies
+ * right of the diagonal inside the written range is unspecified except that the diagonal itself is
+ * exact).  out_d [(row_end-row_begin), >= row_end] with ld = ldk; see smn_unpack_lower_blocks. */
+int smn_kernel_mlp_lower_rows(smn_ctx* ctx, int dtype, int net, int act, int num_hiddens,
+                              double w_std, double b_std, double last_w_std,
+                              const void* x_d, int64_t n, int64_t ldx, int64_t d,
+                              int64_t row_begin, int64_t row_end, int get_mask,
+                              void* nngp_rows_d, void* ntk_rows_d, int64_t ldk);
+
+/* One rank's whole share of the paired layout in ONE launch: the lower trapezoids of row blocks
+ * `rank` and 2*nranks-1-rank (block_rows rows each, a multiple of 128), packed into
+ * nngp_chunk_d / ntk_chunk_d [block_rows^2 * (2*nranks+1)] exactly as smn_unpack_lower_blocks
+ * expects them after the all-gather. */
+int smn_kernel_mlp_shard(smn_ctx* ctx, int dtype, int net, int act, int num_hiddens,
+                         double w_std, double b_std, double last_w_std,
+                         const void* x_d, int64_t n, int64_t ldx, int64_t d,
+                         int nranks, int rank, int64_t block_rows, int get_mask,
+                         void* nngp_chunk_d, void* ntk_chunk_d);
+
 /* The two halves of the build, exposed separately for sweeps that reuse K0 across (w_std,b_std)
  * (experiments/regression/find.py:134-138) and for roofline measurement of the recursion alone.
  * smn_gram: k0_d = x1 x2^T / d (+ q1_d [n1], q2_d [n2] diagonals ||x||^2/d).
@@ -170,6 +190,14 @@ int smn_comm_unique_id(char id_out[128]);
 int smn_comm_init(smn_ctx* ctx, int nranks, int rank, const char id[128]);
 int smn_comm_destroy(smn_ctx* ctx);
 int smn_allgather(smn_ctx* ctx, int dtype, const void* send_d, void* recv_d, int64_t count);
+/* Paired lower-trapezoid layout (host side: sharding.py).  The n rows are cut into 2*nranks blocks
+ * of block_rows rows (a multiple of 128); rank r owns blocks r and 2*nranks-1-r and packs block b
+ * densely as block_rows rows of leading dimension (b+1)*block_rows, low block first, so every rank
+ * contributes block_rows^2 * (2*nranks+1) elements to ONE smn_allgather.  This call scatters the
+ * gathered stage_d [nranks * that count] into the lower triangle (by 128-column tiles) of
+ * k_d [n,n] ld=ldk in natural row order. */
+int smn_unpack_lower_blocks(smn_ctx* ctx, int dtype, const void* stage_d, int64_t n, int nranks,
+                            int64_t block_rows, void* k_d, int64_t ldk);
 
 #ifdef __cplusplus
 }

@@ -63,6 +63,8 @@ PROTOTYPES = {
     "smn_profile_read": [_vp, _i, _pd, _pi],
     "smn_kernel_mlp": [_vp, _i, _i, _i, _i, _d, _d, _d, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _i, _i, _vp, _vp, _i64],
     "smn_kernel_mlp_rows": [_vp, _i, _i, _i, _i, _d, _d, _d, _vp, _i64, _i64, _i64, _i64, _i64, _i, _vp, _vp, _i64],
+    "smn_kernel_mlp_lower_rows": [_vp, _i, _i, _i, _i, _d, _d, _d, _vp, _i64, _i64, _i64, _i64, _i64, _i, _vp, _vp, _i64],
+    "smn_kernel_mlp_shard": [_vp, _i, _i, _i, _i, _d, _d, _d, _vp, _i64, _i64, _i64, _i, _i, _i64, _i, _vp, _vp],
     "smn_gram": [_vp, _i, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _vp, _vp],
     "smn_recursion": [_vp, _i, _i, _i, _i, _d, _d, _d, _vp, _i64, _i64, _i64, _vp, _vp, _i, _i, _vp, _vp, _i64],
     "smn_kernel_cnn": [_vp, _i, _i, _i, _d, _d, _d, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _i, _vp, _i64],
@@ -77,6 +79,7 @@ PROTOTYPES = {
     "smn_comm_init": [_vp, _i, _i, C.c_char_p],
     "smn_comm_destroy": [_vp],
     "smn_allgather": [_vp, _i, _vp, _vp, _i64],
+    "smn_unpack_lower_blocks": [_vp, _i, _vp, _i64, _i, _i64, _vp, _i64],
 }
 for _name, _args in PROTOTYPES.items():
     _fn = getattr(_lib, _name)          # AttributeError here == a symbol the header declares is missing

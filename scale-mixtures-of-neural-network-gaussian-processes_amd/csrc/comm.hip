@@ -90,8 +90,73 @@ extern "C" int smn_allgather(smn_ctx* ctx, int dtype, const void* send_d, void* 
     return SMN_OK;
   }
   Rccl& r = rccl();
+  ProfScope ps(ctx, PROF_MISC, ctx->stream);   // phases_ms.misc of bench.py = gather + unpack
   const int rc = r.AllGather(send_d, recv_d, (size_t)count, dtype == SMN_F64 ? kNcclFloat64 : kNcclFloat32,
                              static_cast<nccl_comm>(ctx->comm), ctx->stream);
   if (rc != 0) return smn_fail(ctx, SMN_ECOMM, "ncclAllGather: %s", r.GetErrorString ? r.GetErrorString(rc) : "?");
+  return SMN_OK;
+}
+
+// ---------------------------------------------------------------- paired lower-trapezoid blocks
+// The balanced symmetric shard (sharding.py: paired layout): the n rows are cut into 2P blocks of
+// `h` rows; rank r builds blocks r and 2P-1-r, each only up to its own last column, packed densely
+// (block b: h rows of leading dimension (b+1)h).  Every rank then holds exactly h*h*(2P+1)
+// elements, so ONE equal-count all-gather moves the lower trapezoids -- about half the bytes of
+// full rows.  This kernel scatters the gathered chunks into the natural row order of K; entries
+// right of the diagonal's 128-column tile are not written.
+namespace {
+
+// VEC elements per lane (VEC = 4 needs 16-byte aligned rows on both sides; the host checks).  blockIdx.y strides
+// over rows, blockIdx.x over 256*VEC-column spans; spans right of the row's diagonal tile leave at once.
+template <typename T, int VEC>
+__global__ void unpack_blocks_kernel(const T* __restrict__ stage, int64_t chunk, int64_t h, int P, int64_t n,
+                                     T* __restrict__ k, int64_t ldk) {
+  const int64_t c = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * VEC;
+  for (int64_t r = blockIdx.y; r < n; r += gridDim.y) {
+    int64_t cend = (r / kTile + 1) * kTile;
+    if (cend > n) cend = n;
+    if (c >= cend) continue;
+    const int64_t b = r / h;
+    const int64_t owner = b < P ? b : 2 * (int64_t)P - 1 - b;
+    const int64_t off = owner * chunk + (b < P ? 0 : h * (owner + 1) * h);
+    const T* src = stage + off + (r - b * h) * ((b + 1) * h) + c;
+    T* dst = k + r * ldk + c;
+    if (VEC > 1 && c + VEC <= cend) {
+      typedef T vec_t __attribute__((ext_vector_type(VEC)));
+      *reinterpret_cast<vec_t*>(dst) = *reinterpret_cast<const vec_t*>(src);
+    } else {
+      for (int v = 0; v < VEC && c + v < cend; ++v) dst[v] = src[v];
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int smn_unpack_lower_blocks(smn_ctx* ctx, int dtype, const void* stage_d, int64_t n, int nranks,
+                                       int64_t block_rows, void* k_d, int64_t ldk) {
+  if (!ctx || !stage_d || !k_d) return SMN_EINVAL;
+  if (dtype != SMN_F32 && dtype != SMN_F64) return smn_fail(ctx, SMN_EINVAL, "bad dtype");
+  if (n <= 0 || nranks <= 0 || block_rows <= 0 || block_rows % kTile || ldk < n ||
+      2 * (int64_t)nranks * block_rows < n)
+    return smn_fail(ctx, SMN_EINVAL, "smn_unpack_lower_blocks: bad geometry (n=%lld ranks=%d block_rows=%lld ldk=%lld)",
+                    (long long)n, nranks, (long long)block_rows, (long long)ldk);
+  const int64_t chunk = block_rows * block_rows * (2 * (int64_t)nranks + 1);
+  const size_t es = dtype_size(dtype);
+  const int vec = (int)(16 / es);
+  const bool aligned = (ldk % vec == 0) && (reinterpret_cast<uintptr_t>(k_d) % 16 == 0) &&
+                       (reinterpret_cast<uintptr_t>(stage_d) % 16 == 0);
+  const int v = aligned ? vec : 1;
+  dim3 g((unsigned)((n + 256 * v - 1) / (256 * v)), (unsigned)(n < 32768 ? n : 32768));
+  ProfScope ps(ctx, PROF_MISC, ctx->stream);
+#define UNPACK(T, V)                                                                                              \
+  hipLaunchKernelGGL((unpack_blocks_kernel<T, V>), g, dim3(256), 0, ctx->stream, static_cast<const T*>(stage_d), \
+                     chunk, block_rows, nranks, n, static_cast<T*>(k_d), ldk)
+  if (dtype == SMN_F64) {
+    if (aligned) UNPACK(double, 2); else UNPACK(double, 1);
+  } else {
+    if (aligned) UNPACK(float, 4); else UNPACK(float, 1);
+  }
+#undef UNPACK
+  SMN_CHECK_LAUNCH(ctx);
   return SMN_OK;
 }

@@ -21,6 +21,7 @@ struct BuildCall {
   const double* q1; const double* q2;
   int symmetric;               // 1: x2 == x1, only tiles with tc <= tr are computed
   int mirror;                  // symmetric only: also store the transposed tile (full matrix out)
+  int lower_skip;              // rectangular only: skip tiles wholly above the global diagonal (row shards)
   int64_t row_off, col_off;    // added to local indices for the row == col (exact diagonal) test
   int exact_diag;              // write the closed-form diagonal where global row == global col
   int store_mode;              // STORE_BOUNDS: write [0,out_rows) x [0,out_cols) only
@@ -28,6 +29,9 @@ struct BuildCall {
   int64_t nv0, aug0, nv1;      // valid(i) = i < nv0 || (aug0 <= i < aug0 + nv1)
   int get_mask;
   void* out_k; void* out_t; int64_t ldo;
+  // paired lower-block shard (symmetric operands): two tile-aligned row blocks [rb,re), each written as
+  // rows x columns [0,re) into its own packed output of leading dimension shard_ld
+  int shard; int64_t shard_rb[2], shard_re[2]; void* shard_k[2]; void* shard_t[2]; int64_t shard_ld[2];
 };
 int run_build(smn_ctx* ctx, const BuildCall& c);
 

@@ -94,12 +94,16 @@ template <typename T>
 struct BuildArgs {
   const T* x1; const T* x2; int64_t ld1, ld2; int kp;
   int tiles_n; int symmetric; int mirror;
+  int lower_skip;             // rectangular grid: drop tiles lying wholly above the global diagonal
   const T* tab1; const T* tab2; int64_t ldt1, ldt2; const T* dg; const T* dgt;
   T inv_d; LayerProg prog;
   int64_t row_off, col_off; int exact_diag;
   int store_mode; int64_t out_rows, out_cols; int64_t nv0, aug0, nv1;
   T* out_k; T* out_t; int64_t ldo;
   int use_map; TileMap map;   // XCD-aware patch order (gemm_nt.hpp)
+  // paired lower-block shard (smn_kernel_mlp_shard): two trapezoids of row tiles, each packed into its own
+  // output with its own leading dimension; operands and tables are the symmetric ones
+  int shard; int sh_b0[2]; int sh_cnt0; T* sh_k[2]; T* sh_t[2]; int64_t sh_ld[2]; int64_t sh_cols[2];
 };
 
 template <typename T, int NET, int ACT, bool NTK>
@@ -108,13 +112,32 @@ __global__ void __launch_bounds__(256, (NTK || sizeof(T) == 8) ? 1 : 2) build_ke
   using Tile = MainTile<T>;
   using M = typename Tile::M;
   int tr, tc;
-  if (a.use_map) {
+  T* out_k = a.out_k; T* out_t = a.out_t;
+  int64_t ldo = a.ldo, out_cols = a.out_cols;
+  if (a.shard) {
+    int idx = blockIdx.x;
+    const int w = idx >= a.sh_cnt0 ? 1 : 0;
+    if (w) idx -= a.sh_cnt0;
+    const int b0 = w ? a.sh_b0[1] : a.sh_b0[0];
+    int t = 0;                                 // row tile b0+t of the block holds b0+t+1 lower tiles
+    while (idx >= b0 + t + 1) { idx -= b0 + t + 1; ++t; }
+    tr = b0 + t;
+    tc = idx;
+    ldo = w ? a.sh_ld[1] : a.sh_ld[0];
+    out_cols = w ? a.sh_cols[1] : a.sh_cols[0];
+    // packed block: row (gr - b0*128) of leading dimension ldo; fold the row shift into the base pointers
+    out_k = w ? a.sh_k[1] : a.sh_k[0];
+    out_t = w ? a.sh_t[1] : a.sh_t[0];
+    if (out_k) out_k -= (int64_t)b0 * kTile * ldo;
+    if (out_t) out_t -= (int64_t)b0 * kTile * ldo;
+  } else if (a.use_map) {
     if (!a.map.decode(blockIdx.x, tr, tc)) return;
   } else if (a.symmetric) {
     tri_decode(blockIdx.x, tr, tc);
   } else {
     tr = blockIdx.x / a.tiles_n;
     tc = blockIdx.x % a.tiles_n;
+    if (a.lower_skip && (int64_t)tc * kTile + a.col_off > (int64_t)tr * kTile + a.row_off + kTile - 1) return;
   }
   const int64_t row0 = (int64_t)tr * kTile, col0 = (int64_t)tc * kTile;
   Tile t;
@@ -207,15 +230,15 @@ __global__ void __launch_bounds__(256, (NTK || sizeof(T) == 8) ? 1 : 2) build_ke
           }
           wr_ok = true;
         } else {
-          wr_ok = gr < a.out_rows && gc < a.out_cols;
+          wr_ok = gr < a.out_rows && gc < out_cols;
         }
         if (wr_ok) {
-          if (a.out_k) a.out_k[gr * a.ldo + gc] = k;
-          if (NTK && a.out_t) a.out_t[gr * a.ldo + gc] = h;
+          if (out_k) out_k[gr * ldo + gc] = k;
+          if (NTK && out_t) out_t[gr * ldo + gc] = h;
         }
-        if (do_mirror && gc < a.out_rows && gr < a.out_cols) {
-          if (a.out_k) a.out_k[gc * a.ldo + gr] = k;
-          if (NTK && a.out_t) a.out_t[gc * a.ldo + gr] = h;
+        if (do_mirror && gc < a.out_rows && gr < out_cols) {
+          if (out_k) out_k[gc * ldo + gr] = k;
+          if (NTK && out_t) out_t[gc * ldo + gr] = h;
         }
       }
 }
@@ -436,6 +459,7 @@ int run_build_t(smn_ctx* ctx, const BuildCall& c) {
   a.ld1 = c.ld1; a.ld2 = c.ld2; a.kp = c.kp;
   const int64_t tm = c.rows1 / kTile, tn = c.rows2 / kTile;
   a.tiles_n = (int)tn; a.symmetric = c.symmetric; a.mirror = c.mirror;
+  a.lower_skip = (!c.symmetric && c.lower_skip) ? 1 : 0;
   a.tab1 = tab1; a.tab2 = tab2; a.ldt1 = tlen; a.ldt2 = tlen; a.dg = dg1; a.dgt = dgt1;
   a.inv_d = (T)(1.0 / (double)c.d); a.prog = prog;
   a.row_off = c.row_off; a.col_off = c.col_off; a.exact_diag = c.exact_diag;
@@ -447,7 +471,26 @@ int run_build_t(smn_ctx* ctx, const BuildCall& c) {
   int64_t ntiles = c.symmetric ? tm * (tm + 1) / 2 : tm * tn;
   a.use_map = 0;
   a.map = TileMap::make(tm, tn, c.symmetric);
-  if (ctx->xcd_map && ntiles >= 512) {
+  a.shard = c.shard;
+  if (c.shard) {
+    if (!c.symmetric) return smn_fail(ctx, SMN_EINVAL, "run_build: shard mode needs the symmetric operands");
+    int64_t cnt[2] = {0, 0};
+    for (int w = 0; w < 2; ++w) {
+      const int64_t rb = c.shard_rb[w], re = c.shard_re[w];
+      if (re > rb && rb % kTile) return smn_fail(ctx, SMN_EINVAL, "run_build: shard block not tile aligned");
+      const int64_t nt = re > rb ? (re - rb + kTile - 1) / kTile : 0, b0 = nt ? rb / kTile : 0;
+      cnt[w] = nt * b0 + nt * (nt + 1) / 2;
+      a.sh_b0[w] = (int)b0;
+      a.sh_k[w] = (c.get_mask & SMN_GET_NNGP) ? static_cast<T*>(c.shard_k[w]) : nullptr;
+      a.sh_t[w] = ntk ? static_cast<T*>(c.shard_t[w]) : nullptr;
+      a.sh_ld[w] = c.shard_ld[w];
+      a.sh_cols[w] = re;
+    }
+    a.sh_cnt0 = (int)cnt[0];
+    ntiles = cnt[0] + cnt[1];
+    if (ntiles == 0) return SMN_OK;
+  }
+  if (ctx->xcd_map && ntiles >= 512 && !a.lower_skip && !a.shard) {
     a.use_map = 1;
     ntiles = a.map.grid;
   }
@@ -567,7 +610,7 @@ static int check_common(smn_ctx* ctx, int dtype, int64_t n1, int64_t n2, int64_t
 static int build_public(smn_ctx* ctx, const BuildSpec& spec, const void* x1, int64_t n1, int64_t ldx1,
                         const void* x2, int64_t n2, int64_t ldx2, int64_t d, int get_mask, int fill,
                         int64_t row_begin, int64_t row_end, void* out_k, void* out_t, int64_t ldk,
-                        void* q1_out, void* q2_out) {
+                        void* q1_out, void* q2_out, bool lower_rows = false) {
   const int dtype = spec.dtype;
   const size_t es = dtype_size(dtype);
   const bool sym = (x2 == nullptr);
@@ -590,16 +633,24 @@ static int build_public(smn_ctx* ctx, const BuildSpec& spec, const void* x1, int
   if (row_end > row_begin) {            // row shard of the symmetric kernel: rows [rb,re) x all columns
     const int64_t rb = row_begin, nr = row_end - row_begin;
     const int64_t rr = round_up(nr, kTile);
-    // the padded copy has r1 rows; a shard's last tile may reach past it -> re-pad from the source
-    void* xr = nullptr;
-    SMN_TRY(smn_workspace(ctx, 3, es * (size_t)kp * (size_t)rr + sizeof(double) * (size_t)rr, &xr));
-    double* qr = static_cast<double*>(xr);
-    char* xrp = reinterpret_cast<char*>(qr + rr);
-    SMN_TRY(pad_rows(ctx, dtype, static_cast<const char*>(x1) + es * (size_t)rb * (size_t)ldx1, nr, ldx1, d, xrp, rr, kp, qr));
-    c.x1p = xrp; c.ld1 = kp; c.rows1 = rr; c.q1 = qr;
+    if (rb % kTile == 0) {              // tile-aligned shard: its rows are a slice of the padded copy
+      c.x1p = x1p + es * (size_t)kp * (size_t)rb; c.ld1 = kp; c.rows1 = rr; c.q1 = q1 + rb;
+    } else {                            // a shard's last tile may reach past the padded copy -> re-pad from the source
+      void* xr = nullptr;
+      SMN_TRY(smn_workspace(ctx, 3, es * (size_t)kp * (size_t)rr + sizeof(double) * (size_t)rr, &xr));
+      double* qr = static_cast<double*>(xr);
+      char* xrp = reinterpret_cast<char*>(qr + rr);
+      SMN_TRY(pad_rows(ctx, dtype, static_cast<const char*>(x1) + es * (size_t)rb * (size_t)ldx1, nr, ldx1, d, xrp, rr, kp, qr));
+      c.x1p = xrp; c.ld1 = kp; c.rows1 = rr; c.q1 = qr;
+    }
     c.x2p = x1p; c.ld2 = kp; c.rows2 = r1; c.q2 = q1;
     c.symmetric = 0; c.mirror = 0; c.row_off = rb; c.col_off = 0; c.exact_diag = 1;
     c.out_rows = nr; c.out_cols = n1;
+    if (lower_rows) {                   // lower trapezoid: columns [0, row_end) only, tiles above the diagonal dropped
+      c.rows2 = round_up(row_end, kTile);
+      c.out_cols = row_end;
+      c.lower_skip = 1;
+    }
     return run_build(ctx, c);
   }
   c.x1p = x1p; c.ld1 = kp; c.rows1 = r1; c.q1 = q1;
@@ -646,6 +697,58 @@ extern "C" int smn_kernel_mlp_rows(smn_ctx* ctx, int dtype, int net, int act, in
   BuildSpec s{dtype, net, act, num_hiddens, w_std, b_std, last_w_std};
   return build_public(ctx, s, x_d, n, ldx, nullptr, 0, 0, d, get_mask, SMN_FILL_FULL, row_begin, row_end,
                       nngp_rows_d, ntk_rows_d, ldk, nullptr, nullptr);
+}
+
+extern "C" int smn_kernel_mlp_lower_rows(smn_ctx* ctx, int dtype, int net, int act, int num_hiddens, double w_std,
+                                         double b_std, double last_w_std, const void* x_d, int64_t n, int64_t ldx,
+                                         int64_t d, int64_t row_begin, int64_t row_end, int get_mask,
+                                         void* nngp_rows_d, void* ntk_rows_d, int64_t ldk) {
+  SMN_TRY(check_common(ctx, dtype, n, 1, d));
+  if (row_begin < 0 || row_end > n || row_end <= row_begin)
+    return smn_fail(ctx, SMN_EINVAL, "bad row range [%lld,%lld)", (long long)row_begin, (long long)row_end);
+  if (ldk < row_end) return smn_fail(ctx, SMN_EINVAL, "ldk %lld < row_end %lld", (long long)ldk, (long long)row_end);
+  BuildSpec s{dtype, net, act, num_hiddens, w_std, b_std, last_w_std};
+  return build_public(ctx, s, x_d, n, ldx, nullptr, 0, 0, d, get_mask, SMN_FILL_FULL, row_begin, row_end,
+                      nngp_rows_d, ntk_rows_d, ldk, nullptr, nullptr, true);
+}
+
+extern "C" int smn_kernel_mlp_shard(smn_ctx* ctx, int dtype, int net, int act, int num_hiddens, double w_std,
+                                    double b_std, double last_w_std, const void* x_d, int64_t n, int64_t ldx,
+                                    int64_t d, int nranks, int rank, int64_t block_rows, int get_mask,
+                                    void* nngp_chunk_d, void* ntk_chunk_d) {
+  SMN_TRY(check_common(ctx, dtype, n, 1, d));
+  if (nranks <= 0 || rank < 0 || rank >= nranks || block_rows <= 0 || block_rows % kTile ||
+      2 * (int64_t)nranks * block_rows < n)
+    return smn_fail(ctx, SMN_EINVAL, "smn_kernel_mlp_shard: bad geometry (n=%lld ranks=%d rank=%d block_rows=%lld)",
+                    (long long)n, nranks, rank, (long long)block_rows);
+  if (!x_d || ((get_mask & SMN_GET_NNGP) && !nngp_chunk_d) || ((get_mask & SMN_GET_NTK) && !ntk_chunk_d))
+    return smn_fail(ctx, SMN_EINVAL, "smn_kernel_mlp_shard: null pointer");
+  const size_t es = dtype_size(dtype);
+  const int64_t kp = k_pad(dtype, d), r1 = round_up(n, kTile), h = block_rows;
+  void* xs = nullptr;
+  SMN_TRY(smn_workspace(ctx, 0, es * (size_t)kp * (size_t)r1 + sizeof(double) * (size_t)r1, &xs));
+  double* q1 = static_cast<double*>(xs);
+  char* x1p = reinterpret_cast<char*>(q1 + r1);
+  SMN_TRY(pad_rows(ctx, dtype, x_d, n, ldx, d, x1p, r1, kp, q1));
+  BuildCall c{};
+  c.spec = BuildSpec{dtype, net, act, num_hiddens, w_std, b_std, last_w_std};
+  c.kp = (int)kp; c.d = d; c.get_mask = get_mask;
+  c.x1p = x1p; c.ld1 = kp; c.rows1 = r1; c.q1 = q1;
+  c.x2p = x1p; c.ld2 = kp; c.rows2 = r1; c.q2 = q1;
+  c.symmetric = 1; c.mirror = 0; c.exact_diag = 1;
+  c.store_mode = STORE_BOUNDS; c.out_rows = n; c.out_cols = n;
+  c.shard = 1;
+  const int64_t blk[2] = {rank, 2 * (int64_t)nranks - 1 - rank};
+  for (int w = 0; w < 2; ++w) {
+    const int64_t rb = blk[w] * h < n ? blk[w] * h : n;
+    c.shard_rb[w] = rb;
+    c.shard_re[w] = rb + h < n ? rb + h : n;
+    c.shard_ld[w] = (blk[w] + 1) * h;
+    const size_t off = w == 0 ? 0 : es * (size_t)(h * (rank + 1) * h);      // low block first, then the high one
+    c.shard_k[w] = nngp_chunk_d ? static_cast<char*>(nngp_chunk_d) + off : nullptr;
+    c.shard_t[w] = ntk_chunk_d ? static_cast<char*>(ntk_chunk_d) + off : nullptr;
+  }
+  return run_build(ctx, c);
 }
 
 extern "C" int smn_gram(smn_ctx* ctx, int dtype, const void* x1_d, int64_t n1, int64_t ldx1, const void* x2_d,

@@ -125,6 +125,123 @@ def test_row_shard_equals_rows_of_full_kernel(L, ctx, dtype):
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("method", ["lower_rows", "shard"])
+@pytest.mark.parametrize("n,world", [(301, 1), (1000, 2), (1500, 3), (2048, 8), (130, 4)])
+def test_paired_lower_block_shards_assemble_the_lower_triangle(L, ctx, dtype, n, world, method):
+    """Multi-GPU build protocol rehearsed on one GPU: every rank's two smn_kernel_mlp_lower_rows
+    calls write its chunk of the staging buffer (the all-gather is then the identity), smn_unpack_lower_blocks
+    assembles K; its lower triangle must be the oracle's and smn_lml must not look at anything else."""
+    from smnngp import sharding as S
+    rng = np.random.default_rng(n + world)
+    d = 24
+    xh = rng.standard_normal((n, d)).astype(dtype)
+    yh = rng.standard_normal(n).astype(dtype)
+    x = ctx.to_device(xh); y = ctx.to_device(yh)
+    code, es = L.dtype_code(dtype), np.dtype(dtype).itemsize
+    chunk = S.paired_chunk_elems(n, world)
+    stage = ctx.to_device(np.full(world * chunk, np.nan, dtype))            # NaN poison: unwritten = visible
+    k = ctx.to_device(np.full((n, n), np.nan, dtype))
+    for r in range(world):
+        if method == "shard":                                                # one launch per rank (bench.py's form)
+            ctx.call("smn_kernel_mlp_shard", code, L.NET_MLP, L.ACT["relu"], 2, 1.2, 0.1, 1.0, x.ptr, n, d, d,
+                     world, r, S.block_rows(n, world), L.GET_NNGP, C.c_void_p(stage.ptr.value + r * chunk * es), None)
+            continue
+        for b in S.paired_blocks(world, r):
+            rb, re = S.block_range(n, world, b)
+            if re <= rb:
+                continue
+            off, ld = S.block_offset(n, world, b)
+            ctx.call("smn_kernel_mlp_lower_rows", code, L.NET_MLP, L.ACT["relu"], 2, 1.2, 0.1, 1.0, x.ptr, n, d, d,
+                     rb, re, L.GET_NNGP, C.c_void_p(stage.ptr.value + off * es), None, ld)
+    ctx.call("smn_unpack_lower_blocks", code, stage.ptr, n, world, S.block_rows(n, world), k.ptr, n)
+    ref = O.mlp_kernel(xh.astype(np.float64), None, 2, "relu", 1.2, 0.1, 1.0)
+    got = k.numpy().astype(np.float64)
+    il = np.tril_indices(n)
+    assert np.isfinite(got[il]).all()
+    assert relerr(got[il], ref[il]) < RTOL[dtype]
+    iu = np.triu_indices(n, S.TILE)                                          # beyond the diagonal tile: untouched
+    assert np.isnan(got[iu]).all()
+    eps = 1e-3 if dtype == np.float32 else 1e-6
+    lp, quad, logdet, info = C.c_double(), C.c_double(), C.c_double(), C.c_int()
+    ctx.call("smn_lml", code, k.ptr, n, n, y.ptr, eps, 0.0, 1.0, C.byref(lp), C.byref(quad), C.byref(logdet), C.byref(info))
+    want = O.mvn_logpdf(yh.astype(np.float64), ref + eps * np.eye(n))
+    assert info.value == 0 and abs(lp.value - want) < (2e-3 if dtype == np.float32 else 1e-8) * abs(want)
+
+
+def test_build_lower_sharded_single_rank_and_bad_geometry(L, ctx):
+    from smnngp import sharding as S
+    rng = np.random.default_rng(3)
+    n, d = 700, 16
+    xh = rng.standard_normal((n, d))
+    x = ctx.to_device(xh)
+    stage = ctx.empty((S.paired_chunk_elems(n, 1),), np.float64)
+    k = ctx.to_device(np.zeros((n, n)))
+    S.build_lower_sharded(ctx, L.F64, 8, L.NET_MLP, L.ACT["erf"], 3, 1.1, 0.2, 0.9, x.ptr, n, d, d, 0, 1, stage.ptr, k.ptr, n)
+    ref = O.mlp_kernel(xh, None, 3, "erf", 1.1, 0.2, 0.9)
+    il = np.tril_indices(n)
+    assert relerr(k.numpy()[il], ref[il]) < RTOL[np.float64]
+    with pytest.raises(L.SmnError):
+        ctx.call("smn_unpack_lower_blocks", L.F64, stage.ptr, n, 1, 100, k.ptr, n)        # block_rows not a tile multiple
+    with pytest.raises(L.SmnError):
+        ctx.call("smn_unpack_lower_blocks", L.F64, stage.ptr, n, 1, 128, k.ptr, n)        # 2*1*128 rows < n
+    with pytest.raises(L.SmnError):
+        ctx.call("smn_kernel_mlp_lower_rows", L.F64, L.NET_MLP, L.ACT["erf"], 3, 1.1, 0.2, 0.9, x.ptr, n, d, d,
+                 0, 256, L.GET_NNGP, stage.ptr, None, 128)                                 # ldk < row_end
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_shard_build_ntk_erf(L, ctx, dtype):
+    """smn_kernel_mlp_shard with both outputs (C5's shape of work: erf NNGP + NTK), three ranks on one GPU."""
+    from smnngp import sharding as S
+    rng = np.random.default_rng(11)
+    n, d, world = 900, 40, 3
+    xh = rng.standard_normal((n, d)).astype(dtype)
+    x = ctx.to_device(xh)
+    code, es = L.dtype_code(dtype), np.dtype(dtype).itemsize
+    chunk, h = S.paired_chunk_elems(n, world), S.block_rows(n, world)
+    sk = ctx.to_device(np.full(world * chunk, np.nan, dtype)); st = ctx.to_device(np.full(world * chunk, np.nan, dtype))
+    for r in range(world):
+        ctx.call("smn_kernel_mlp_shard", code, L.NET_MLP, L.ACT["erf"], 3, 1.3, 0.2, 0.8, x.ptr, n, d, d, world, r, h,
+                 L.GET_NNGP | L.GET_NTK, C.c_void_p(sk.ptr.value + r * chunk * es), C.c_void_p(st.ptr.value + r * chunk * es))
+    k = ctx.to_device(np.zeros((n, n), dtype)); t = ctx.to_device(np.zeros((n, n), dtype))
+    ctx.call("smn_unpack_lower_blocks", code, sk.ptr, n, world, h, k.ptr, n)
+    ctx.call("smn_unpack_lower_blocks", code, st.ptr, n, world, h, t.ptr, n)
+    rk, rt = O.mlp_kernel(xh.astype(np.float64), None, 3, "erf", 1.3, 0.2, 0.8, get=("nngp", "ntk"))
+    il = np.tril_indices(n)
+    assert relerr(k.numpy()[il], rk[il]) < RTOL[dtype]
+    assert relerr(t.numpy()[il], rt[il]) < RTOL[dtype] * 5
+    with pytest.raises(L.SmnError):
+        ctx.call("smn_kernel_mlp_shard", code, L.NET_MLP, L.ACT["erf"], 3, 1.3, 0.2, 0.8, x.ptr, n, d, d, world, 3, h,
+                 L.GET_NNGP, sk.ptr, None)                                   # rank out of range
+    with pytest.raises(L.SmnError):
+        ctx.call("smn_kernel_mlp_shard", code, L.NET_MLP, L.ACT["erf"], 3, 1.3, 0.2, 0.8, x.ptr, n, d, d, world, 0, h,
+                 L.GET_NNGP | L.GET_NTK, sk.ptr, None)                       # NTK asked for, no buffer
+
+
+def test_rccl_single_rank_communicator_allgather(L):
+    """librccl is dlopen'ed and driven through its C ABI (unique id by value, comm init, all-gather, destroy).
+    One rank is all a 1-GPU box can host; it still exercises every RCCL entry point the N>1 path uses."""
+    c = L.Context(0)
+    uid = C.create_string_buffer(128)
+    assert L._lib.smn_comm_unique_id(uid) == 0
+    c.call("smn_comm_init", 1, 0, uid)
+    with pytest.raises(L.SmnError):
+        c.call("smn_comm_init", 1, 0, uid)                                   # already initialised
+    src = np.arange(4096, dtype=np.float32)
+    a = c.to_device(src); b = c.to_device(np.zeros_like(src))
+    c.call("smn_allgather", L.F32, a.ptr, b.ptr, src.size)                   # out of place
+    assert (b.numpy() == src).all()
+    c.call("smn_allgather", L.F32, a.ptr, a.ptr, src.size)                   # in place (the bench's form)
+    assert (a.numpy() == src).all()
+    a64 = c.to_device(src.astype(np.float64)); b64 = c.to_device(np.zeros(src.size))
+    c.call("smn_allgather", L.F64, a64.ptr, b64.ptr, src.size)
+    assert (b64.numpy() == src).all()
+    c.call("smn_comm_destroy")
+    c.call("smn_allgather", L.F32, a.ptr, b.ptr, src.size)                   # no communicator: plain copy
+    assert (b.numpy() == src).all()
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("act", ["relu", "erf"])
 @pytest.mark.parametrize("shape,layers", [((7, 5, 4, 3), 2), ((9, 8, 8, 1), 4), ((5, 1, 1, 6), 3), ((3, 32, 32, 3), 1)])
 def test_cnn_kernel(dtype, act, shape, layers):

@@ -78,3 +78,111 @@ def test_world_size_2_gloo_build_gather_lml(n):
     assert np.allclose(k, ref, rtol=1e-12, atol=1e-14)
     ref_lml = O.mvn_logpdf(y, ref + 1e-3 * np.eye(n))
     assert abs(lml - ref_lml) < 1e-9 * abs(ref_lml) and abs(lml_max - lml) < 1e-9 * abs(lml)
+
+
+# ------------------------------------------------------------------ paired lower-trapezoid layout
+def _unpack_numpy(stage, n, world, S):
+    """NumPy restatement of smn_unpack_lower_blocks (tile-granular lower triangle)."""
+    k = np.full((n, n), np.nan)
+    for b in range(2 * world):
+        rb, re = S.block_range(n, world, b)
+        off, ld = S.block_offset(n, world, b)
+        for r in range(rb, re):
+            cend = min(n, (r // S.TILE + 1) * S.TILE)
+            k[r, :cend] = stage[off + (r - rb) * ld: off + (r - rb) * ld + cend]
+    return k
+
+
+def test_paired_layout_covers_rows_once_is_balanced_and_packs_without_overlap():
+    from smnngp import sharding as S
+    for n, w in [(16384, 8), (16384, 2), (32768, 8), (4096, 4), (301, 2), (1000, 3), (128, 8), (1, 1)]:
+        h = S.block_rows(n, w)
+        assert h % S.TILE == 0 and 2 * w * h >= n
+        seen = np.zeros(n, dtype=int)
+        used = np.zeros(w * S.paired_chunk_elems(n, w), dtype=np.int8) if n <= 4096 else None
+        work = []
+        for r in range(w):
+            lo, hi = S.paired_blocks(w, r)
+            assert S.block_owner(w, lo) == r and S.block_owner(w, hi) == r and lo + hi == 2 * w - 1
+            tiles = 0
+            for b in (lo, hi):
+                rb, re = S.block_range(n, w, b)
+                seen[rb:re] += 1
+                off, ld = S.block_offset(n, w, b)
+                assert ld == (b + 1) * h and ld >= re                       # a packed row holds columns [0, re)
+                assert r * S.paired_chunk_elems(n, w) <= off
+                assert off + h * ld <= (r + 1) * S.paired_chunk_elems(n, w)  # stays inside the owner's chunk
+                if used is not None:
+                    used[off: off + h * ld] += 1
+                tiles += sum(t + 1 for t in range(rb // S.TILE, -(-re // S.TILE)))
+            work.append(tiles)
+        assert (seen == 1).all()
+        if used is not None:
+            assert used.max() <= 1
+        if n % (2 * w * S.TILE) == 0:                                       # exact split: perfectly balanced
+            assert max(work) == min(work)
+            total = (n // S.TILE) * (n // S.TILE + 1) // 2
+            assert sum(work) == total
+    with pytest.raises(ValueError):
+        S.paired_blocks(2, 2)
+    with pytest.raises(ValueError):
+        S.block_owner(2, 4)
+
+
+def _paired_worker(rank, world, port, n, d, q):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    from oracle import nngp_oracle as O
+    from smnngp import sharding as S
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(0)
+        x = rng.standard_normal((n, d)); y = rng.standard_normal(n)
+        chunk = S.paired_chunk_elems(n, world)
+        stage = torch.full((world * chunk,), float("nan"), dtype=torch.float64)
+        sn = stage.numpy()
+        for b in S.paired_blocks(world, rank):
+            rb, re = S.block_range(n, world, b)
+            if re <= rb:
+                continue
+            rows = O.mlp_kernel(x[rb:re], x[:re], 2, "relu", 1.2, 0.3, 1.0)   # stand-in for smn_kernel_mlp_lower_rows
+            rows[np.arange(re - rb), np.arange(rb, re)] = O.diag_recursion((x[rb:re] ** 2).sum(1) / d, 2, "relu", 1.2, 0.3, 1.0)
+            off, ld = S.block_offset(n, world, b)
+            for i in range(re - rb):
+                sn[off + i * ld: off + i * ld + re] = rows[i]
+        send = stage[rank * chunk: (rank + 1) * chunk].clone()
+        dist.all_gather_into_tensor(stage, send)
+        k = _unpack_numpy(stage.numpy(), n, world, S)
+        kl = np.tril(k)
+        ks = kl + np.tril(kl, -1).T
+        lml = O.mvn_logpdf(y, ks + 1e-3 * np.eye(n))
+        if rank == 0:
+            q.put((ks, lml))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [300, 513])
+def test_world_size_2_gloo_paired_lower_blocks(n):
+    pytest.importorskip("torch")
+    import torch.multiprocessing as mp
+    from oracle import nngp_oracle as O
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    d = 5
+    procs = [ctx.Process(target=_paired_worker, args=(r, 2, port, n, d, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    k, lml = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((n, d)); y = rng.standard_normal(n)
+    ref = O.mlp_kernel(x, None, 2, "relu", 1.2, 0.3, 1.0)
+    assert np.allclose(k, ref, rtol=1e-12, atol=1e-14)
+    ref_lml = O.mvn_logpdf(y, ref + 1e-3 * np.eye(n))
+    assert abs(lml - ref_lml) < 1e-9 * abs(ref_lml)
