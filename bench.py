@@ -305,9 +305,18 @@ def main():
                 ctx.call("smn_profile_enable", 0)
                 rec_ms = ms.value / max(cnt.value, 1)
                 nbytes = 2.0 * n * n * np.dtype(np_dtype).itemsize
-                others["recursion_kernel (stand-alone %d-layer %s map over a stored K0)" % (nl, args.act)] = {
+                rec_traffic = None
+                if (args.n, args.layers, args.act, args.dtype) == (16384, 4, "relu", "f32"):
+                    try:
+                        with open(os.path.join(ROOT, "profiles", "r01e_pmc_recursion.json")) as f:
+                            rec_traffic = json.load(f)["traffic_bytes_per_launch"]
+                    except Exception:
+                        rec_traffic = None
+                # achieved = SURVEY 8(d) algorithmic bytes (read N^2 + write N^2) / time; the symmetric kernel reads
+                # only the lower tiles, so the bytes it really moves (`traffic`, PMC) are ~0.77x of that
+                others["recursion_sym_kernel (stand-alone %d-layer %s map over a stored symmetric K0)" % (nl, args.act)] = {
                     "bound": "hbm", "achieved": nbytes / (rec_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                    "frac": nbytes / (rec_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "ms": rec_ms}
+                    "frac": nbytes / (rec_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": rec_traffic, "ms": rec_ms}
                 del k0, kk
             except Exception as e:  # the probe must never break the bench line
                 others["recursion_kernel"] = {"error": str(e)}

@@ -250,6 +250,7 @@ struct RecArgs {
   const T* tab1; const T* tab2; int64_t ldt1, ldt2; const T* dg; const T* dgt;
   LayerProg prog; int exact_diag;
   T* out_k; T* out_t; int64_t ldo; int rows_per_block;
+  int sym_tiles;   // recursion_sym_kernel: one workgroup per lower 64x64 tile
 };
 
 // Block = 4 waves; blockIdx.x -> strip of 64*VEC columns, blockIdx.y -> group of rows.  A wave
@@ -366,6 +367,146 @@ __global__ void __launch_bounds__(256) recursion_kernel(RecArgs<T> a) {
             if (NTK && a.out_t) a.out_t[rr * a.ldo + gc + e] = hv[r][e];
           }
       }
+    }
+  }
+}
+
+// Symmetric form (x2 == x1, full output): one workgroup per LOWER 64x64 tile.  The element chains run once per
+// unordered pair; the tile is written straight (16-byte stores) and, through an LDS transpose, mirrored into
+// the upper triangle.  Halves the VALU work that bounds the 4-layer map and the K0 bytes read.
+template <typename T, int NET, int ACT, bool NTK>
+__global__ void __launch_bounds__(256) recursion_sym_kernel(RecArgs<T> a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int TS = 64, VEC = 16 / sizeof(T);
+  constexpr int LPR = TS / VEC;        // lanes per tile row
+  constexpr int RPP = 256 / LPR;       // tile rows covered per pass of the workgroup
+  constexpr int NP = TS / RPP;         // passes
+  constexpr int LDT = TS + 1;          // transpose buffer stride: scalar LDS accesses, conflict-free both ways
+  constexpr bool FAST = ElemProg<T, NET, ACT, NTK>::FAST;
+  using vec_t = typename Mfma<T>::vec_t;
+  const int tid = threadIdx.x;
+  const int nsets = a.prog.nsets;
+  const int trows = nsets * 2 + 1;
+  T* scol = reinterpret_cast<T*>(smem);          // [trows][TS] factors of the tile's columns
+  T* srow = scol + trows * TS;                   // [trows][TS] factors of the tile's rows
+  T* tbk = srow + trows * TS;                    // [TS][LDT] tile of K for the mirror
+  T* tbt = tbk + TS * LDT;                       // [TS][LDT] tile of Theta (NTK only)
+  int tr, tc;
+  tri_decode(blockIdx.x, tr, tc);
+  const int64_t row0 = (int64_t)tr * TS, col0 = (int64_t)tc * TS, n = a.n1;
+  const int lr0 = tid / LPR, lc = (tid % LPR) * VEC;
+  const int64_t gc = col0 + lc;
+  const bool cfull = gc + VEC <= n;
+  vec_t kv[NP], hv[NP];
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {                 // every load of the tile in flight before the tables are staged
+    const int64_t gr = row0 + p * RPP + lr0;
+    if (gr < n && cfull) {
+      kv[p] = *reinterpret_cast<const vec_t*>(a.k0 + gr * a.ldk0 + gc);
+    } else {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) kv[p][e] = (gr < n && gc + e < n) ? a.k0[gr * a.ldk0 + gc + e] : T(0);
+    }
+  }
+  for (int idx = tid; idx < trows * TS; idx += 256) {
+    const int s2 = idx / TS, r = idx % TS;
+    const int g2 = s2 < nsets * 2 ? s2 : nsets * 2 + 1;
+    scol[idx] = col0 + r < n ? a.tab1[(int64_t)g2 * a.ldt1 + col0 + r] : T(0);
+    srow[idx] = row0 + r < n ? a.tab1[(int64_t)g2 * a.ldt1 + row0 + r] : T(0);
+  }
+  __syncthreads();
+  const ElemProg<T, NET, ACT, NTK> prog(a.prog);
+  const bool mirror = tr != tc;
+#pragma unroll
+  for (int pp = 0; pp < NP; pp += 2) {           // two passes at a time: 2 * VEC independent chains per lane
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        T k = kv[pp + r][e], h = T(0);
+        prog.pre(k, h);
+        kv[pp + r][e] = k;
+        hv[pp + r][e] = h;
+      }
+    for (int s = 0; s < nsets; ++s) {
+      const vec_t cr = *reinterpret_cast<const vec_t*>(scol + (2 * s) * TS + lc);
+      const vec_t cs = *reinterpret_cast<const vec_t*>(scol + (2 * s + 1) * TS + lc);
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int lr = (pp + r) * RPP + lr0;
+        const T ri = srow[(2 * s) * TS + lr], si = srow[(2 * s + 1) * TS + lr];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          T k = kv[pp + r][e], h = hv[pp + r][e];
+          prog.step(s, k, h, ri * cr[e], si * cs[e]);
+          kv[pp + r][e] = k;
+          hv[pp + r][e] = h;
+        }
+      }
+    }
+    vec_t sgc = vec_t{};
+    if (FAST) sgc = *reinterpret_cast<const vec_t*>(scol + (2 * nsets) * TS + lc);
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int lr = (pp + r) * RPP + lr0;
+      const int64_t gr = row0 + lr;
+      const T sgr = FAST ? srow[(2 * nsets) * TS + lr] : T(0);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        T k = kv[pp + r][e], h = hv[pp + r][e];
+        prog.post(k, h, sgr * sgc[e]);
+        if (gr == gc + e) {
+          k = a.dg[gr < n ? gr : 0];
+          if (NTK) h = a.dgt[gr < n ? gr : 0];
+        }
+        kv[pp + r][e] = k;
+        hv[pp + r][e] = h;
+        if (mirror) {
+          tbk[lr * LDT + lc + e] = k;
+          if (NTK) tbt[lr * LDT + lc + e] = h;
+        }
+      }
+      if (gr < n) {
+        if (cfull) {
+          if (a.out_k) *reinterpret_cast<vec_t*>(a.out_k + gr * a.ldo + gc) = kv[pp + r];
+          if (NTK && a.out_t) *reinterpret_cast<vec_t*>(a.out_t + gr * a.ldo + gc) = hv[pp + r];
+        } else {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e)
+            if (gc + e < n) {
+              if (a.out_k) a.out_k[gr * a.ldo + gc + e] = kv[pp + r][e];
+              if (NTK && a.out_t) a.out_t[gr * a.ldo + gc + e] = hv[pp + r][e];
+            }
+        }
+      }
+    }
+  }
+  if (!mirror) return;                           // uniform per workgroup
+  __syncthreads();
+  // mirrored store: output row col0 + cc takes the tile's column cc; lanes again own VEC consecutive output columns
+  const int64_t oc = row0 + lc;
+  const bool ofull = oc + VEC <= n;
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const int cc = p * RPP + lr0;
+    const int64_t orow = col0 + cc;
+    if (orow >= n) continue;
+    vec_t vk, vt = vec_t{};
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      vk[e] = tbk[(lc + e) * LDT + cc];
+      if (NTK) vt[e] = tbt[(lc + e) * LDT + cc];
+    }
+    if (ofull) {
+      if (a.out_k) *reinterpret_cast<vec_t*>(a.out_k + orow * a.ldo + oc) = vk;
+      if (NTK && a.out_t) *reinterpret_cast<vec_t*>(a.out_t + orow * a.ldo + oc) = vt;
+    } else {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e)
+        if (oc + e < n) {
+          if (a.out_k) a.out_k[orow * a.ldo + oc + e] = vk[e];
+          if (NTK && a.out_t) a.out_t[orow * a.ldo + oc + e] = vt[e];
+        }
     }
   }
 }
@@ -502,6 +643,16 @@ int run_build_t(smn_ctx* ctx, const BuildCall& c) {
 
 template <typename T, int NET, int ACT, bool NTK>
 int launch_rec_t(smn_ctx* ctx, const RecArgs<T>& a, dim3 grid, size_t lds) {
+  if (a.sym_tiles) {
+    auto kern = recursion_sym_kernel<T, NET, ACT, NTK>;
+    SMN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    {
+      ProfScope ps(ctx, PROF_RECURSION, ctx->stream);
+      hipLaunchKernelGGL(kern, grid, dim3(256), lds, ctx->stream, a);
+    }
+    SMN_CHECK_LAUNCH(ctx);
+    return SMN_OK;
+  }
   {
     ProfScope ps(ctx, PROF_RECURSION, ctx->stream);
     hipLaunchKernelGGL((recursion_kernel<T, NET, ACT, NTK>), grid, dim3(256), lds, ctx->stream, a);
@@ -574,6 +725,17 @@ int recursion_t(smn_ctx* ctx, const BuildSpec& spec, const void* k0, int64_t n1,
   if (ldk0 % (16 / sizeof(T)) || ldk % (16 / sizeof(T)) || (reinterpret_cast<uintptr_t>(k0) & 15) ||
       (a.out_k && (reinterpret_cast<uintptr_t>(a.out_k) & 15)) || (a.out_t && (reinterpret_cast<uintptr_t>(a.out_t) & 15)))
     return smn_fail(ctx, SMN_EINVAL, "smn_recursion: k0/out must be 16-byte aligned with ld %% %d == 0", (int)(16 / sizeof(T)));
+  a.sym_tiles = 0;
+  if (symmetric && n1 == n2 && ctx->rec_sym) {
+    constexpr int TS = 64;
+    const int64_t t = (n1 + TS - 1) / TS;
+    const int64_t ntiles = t * (t + 1) / 2;
+    if (ntiles < (int64_t)INT32_MAX) {
+      a.sym_tiles = 1;
+      const size_t slds = sizeof(T) * ((size_t)(prog.nsets * 2 + 1) * 2 * TS + (size_t)(want_ntk ? 2 : 1) * TS * (TS + 1));
+      return launch_rec<T>(ctx, a, dim3((unsigned)ntiles), slds, want_ntk);
+    }
+  }
   return launch_rec<T>(ctx, a, grid, lds, want_ntk);
 }
 

@@ -111,6 +111,47 @@ def test_gram_then_recursion_equals_fused(L, ctx, dtype):
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("n", [64, 203, 516])
+@pytest.mark.parametrize("net,act,layers", [("mlp", "relu", 4), ("mlp", "erf", 2), ("resnet", "relu", 2)])
+def test_symmetric_recursion_lower_tiles_and_mirror(L, ctx, dtype, n, net, act, layers):
+    """smn_recursion on a symmetric K0 (find.py's sweep form): the lower-tile + LDS-mirror kernel must fill BOTH
+    triangles, match the oracle, be exactly symmetric, and agree with the row-streaming kernel it replaces."""
+    import os
+    rng = np.random.default_rng(n)
+    d, ld = 24, (n + 3) // 4 * 4                                         # 16-byte aligned rows (API contract)
+    xh = rng.standard_normal((n, d)).astype(dtype)
+    code = L.dtype_code(dtype)
+    netc = L.NET_MLP if net == "mlp" else L.NET_DENSE_RESNET
+    ofn = O.mlp_kernel if net == "mlp" else O.dense_resnet_kernel
+    rk, rt = ofn(xh.astype(np.float64), None, layers, act, 1.2, 0.3, 0.9, ("nngp", "ntk"))
+    got = {}
+    for sym in ("1", "0"):
+        os.environ["SMN_REC_SYM"] = sym
+        try:
+            c = L.Context(0)                                                 # the flag is read at context creation
+        finally:
+            del os.environ["SMN_REC_SYM"]
+        x = c.to_device(xh)
+        k0 = c.empty((n, ld), dtype); q = c.empty((n,), dtype)
+        c.call("smn_gram", code, x.ptr, n, d, None, 0, 0, d, k0.ptr, ld, q.ptr, None)
+        k = c.to_device(np.full((n, ld), np.nan, dtype)); t = c.to_device(np.full((n, ld), np.nan, dtype))
+        c.call("smn_recursion", code, netc, L.ACT[act], layers, 1.2, 0.3, 0.9, k0.ptr, n, n, ld, q.ptr, q.ptr,
+               1, L.GET_NNGP | L.GET_NTK, k.ptr, t.ptr, ld)
+        got[sym] = (k.numpy()[:, :n], t.numpy()[:, :n])
+        assert relerr(got[sym][0], rk) < RTOL[dtype] and relerr(got[sym][1], rt) < RTOL[dtype] * 5
+        k1 = c.to_device(np.full((n, ld), np.nan, dtype))                    # NNGP only (the f32 ReLU fast path)
+        c.call("smn_recursion", code, netc, L.ACT[act], layers, 1.2, 0.3, 0.9, k0.ptr, n, n, ld, q.ptr, q.ptr,
+               1, L.GET_NNGP, k1.ptr, None, ld)
+        k1h = k1.numpy()[:, :n]
+        assert relerr(k1h, rk) < RTOL[dtype]
+        if sym == "1":
+            assert (got[sym][0] == got[sym][0].T).all() and (got[sym][1] == got[sym][1].T).all()
+            assert (k1h == k1h.T).all()
+    il = np.tril_indices(n)
+    assert relerr(got["1"][0][il], got["0"][0][il]) < (1e-6 if dtype == np.float32 else 1e-14)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_row_shard_equals_rows_of_full_kernel(L, ctx, dtype):
     rng = np.random.default_rng(6)
     n, d = 301, 24
