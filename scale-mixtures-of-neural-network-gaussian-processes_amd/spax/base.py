@@ -41,15 +41,17 @@ class ConstraintTrainVar(TrainVar):
 
 
 class Module:
-    """Minimal objax.Module stand-in: vars() collects TrainVars by dotted name (the keys the
-    reference's checkpoint reader matches by last component, experiments/regression/test.py:38-43)."""
+    """Minimal objax.Module stand-in.  vars() names follow objax's scoping rule -- "(SPR).kernel(NNGPKernel).w_std",
+    "(SPR).eps", "(SPR).likelihood(StudentTLikelihood).a" -- so a collection saved here carries the names a
+    reference run would have written, and the reference's checkpoint reader (which matches by the last dotted
+    component, experiments/regression/test.py:38-43) finds the same keys."""
 
-    def vars(self, prefix=""):
+    def vars(self, scope=""):
         out = {}
+        scope += "(%s)." % type(self).__name__
         for k, v in vars(self).items():
-            name = "%s.%s" % (prefix, k) if prefix else k
             if isinstance(v, TrainVar):
-                out["(%s).%s" % (type(self).__name__, name)] = v
+                out[scope + k] = v
             elif isinstance(v, Module):
-                out.update(v.vars(name))
+                out.update(v.vars(scope + k))
         return out

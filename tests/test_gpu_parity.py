@@ -581,3 +581,47 @@ def test_finite_difference_train_step():
     step = train.build_train_step(model)
     losses = [step(1e-2) for _ in range(12)]
     assert model.loss() < losses[0] - 1e-4 and all(np.isfinite(losses))
+
+
+# ----------------------------------------------------------------------------- reference checkpoints
+@pytest.mark.parametrize("method,network", [("tp", None), ("gp", "resnet")])
+def test_restore_spr_from_a_reference_style_run_directory(tmp_path, method, network):
+    """A run directory laid out like the reference's (objax names, RAW softplus-inverse tensors, pickled args,
+    eps stored as diag_reg, last_w_std only in the args) is rebuilt the way regression/test.py:89-130 does, and
+    evaluates to the oracle's numbers at the constrained hyper-parameters; saving our own model round-trips."""
+    import os
+    from smnngp import checkpoint as CK
+    rng = np.random.default_rng(21)
+    n, t, d = 180, 25, 5
+    x, xt = rng.standard_normal((n, d)), rng.standard_normal((t, d))
+    y, yt = rng.standard_normal(n), rng.standard_normal(t)
+    hyp = dict(w_std=1.3, b_std=0.4, eps=2e-2, a=1.7, b=2.4)
+    raw = {k: np.array(O.softplus_inverse(v), np.float32) for k, v in hyp.items()}
+    names = ["(SPR).kernel(NNGPKernel).w_std", "(SPR).kernel(NNGPKernel).b_std", "(SPR).diag_reg"]
+    vals = [raw["w_std"], raw["b_std"], raw["eps"]]
+    if method == "tp":
+        names += ["(SPR).likelihood(StudentTLikelihood).a", "(SPR).likelihood(StudentTLikelihood).b"]
+        vals += [raw["a"], raw["b"]]
+    d1 = str(tmp_path / "ref_run"); os.makedirs(d1)
+    lw_raw = 0.8                                                            # test.py assigns the arg as the raw value
+    np.savez(os.path.join(d1, "012.npz"), names=np.array(names), **{str(i): v for i, v in enumerate(vals)})
+    np.save(os.path.join(d1, "meta.npy"), dict(args=dict(method=method, network=network, num_hiddens=2, activation="erf",
+                                                         data_name="syn", last_w_std=lw_raw)))
+    model, ctx_args = CK.restore_spr(d1, x, y, 0.3, 1.9, dtype=np.float64)
+    assert ctx_args["activation"] == "erf"
+    okw = dict(kernel=network or "mlp", num_hiddens=2, act="erf", w_std=float(O.softplus(raw["w_std"])),
+               b_std=float(O.softplus(raw["b_std"])), last_w_std=float(O.softplus(lw_raw)), eps=float(O.softplus(raw["eps"])),
+               method=method, alpha=float(O.softplus(raw["a"])), beta=float(O.softplus(raw["b"])))
+    rl = O.spr_loss(x, y, **okw)
+    rn = O.spr_test_nll(x, y, xt, yt, 0.3, 1.9, **okw)
+    assert abs(model.loss() - rl) < 1e-7 * max(1.0, abs(rl))
+    assert abs(model.test_nll(xt, yt) - rn) < 1e-5 * max(1.0, abs(rn))
+    # our own writer -> our own reader: identical raw values, identical loss
+    d2 = str(tmp_path / "own_run")
+    ck = CK.Checkpointer(d2)
+    assert ck.step(1, model.loss(), model.vars())
+    CK.save_meta(d2, ctx_args)
+    model2, _ = CK.restore_spr(d2, x, y, 0.3, 1.9, dtype=np.float64)
+    for k, v in model.vars().items():
+        assert float(model2.vars()[k].value) == float(v.value)
+    assert model2.loss() == model.loss()
