@@ -182,6 +182,27 @@ int smn_spr_predict(smn_ctx* ctx, int dtype, int net, int act, int num_hiddens,
                     void* mean_d, void* cov_d, int64_t ldcov,
                     double* quad_h, double* logdet_h, int* info_h);
 
+/* ---- hyper-parameter gradients of the log-marginal likelihood ----
+ * What objax.GradValues(model.loss, vars) supplies to experiments/regression/train.py:61-67.
+ * With K~ = K(w_std, b_std, last_w_std) + eps I, alpha = K~^-1 y and G = coef * alpha alpha^T - K~^-1:
+ *     terms_h[0..3] = sum_ij G_ij dK~_ij/d{w_std, b_std, last_w_std, eps}      (so d logpdf/d theta = terms/2)
+ * smn_lml_grad_terms: the contraction alone.  k0_d [n,n] = X X^T / d and q_d [n] its diagonal (smn_gram),
+ *   neg_kinv_d [n,n] = -K~^-1 and alpha_d [n] as smn_predict returns them for K_td = I, K_tt = 0
+ *   (covariance = -K~^-1, mean = alpha).  coef = 1 (Gaussian) or (df+n)/((df + quad/scale) scale) (Student-t).
+ * smn_spr_loss_grad: everything from X and y (MLP / dense ResNet kernels): also returns quad = y^T K~^-1 y,
+ *   logdet K~ and info, from which the host forms the log-pdf and the derivatives w.r.t. (a, b).
+ *   On a non-PD matrix info > 0 and the terms are NaN. */
+int smn_lml_grad_terms(smn_ctx* ctx, int dtype, int net, int act, int num_hiddens,
+                       double w_std, double b_std, double last_w_std,
+                       const void* k0_d, int64_t n, int64_t ldk0, const void* q_d,
+                       const void* neg_kinv_d, int64_t ldkinv, const void* alpha_d,
+                       double coef, double terms_h[4]);
+int smn_spr_loss_grad(smn_ctx* ctx, int dtype, int net, int act, int num_hiddens,
+                      double w_std, double b_std, double last_w_std,
+                      const void* x_d, int64_t n, int64_t ldx, int64_t d, const void* y_d,
+                      double eps_abs, double df, double scale,
+                      double* quad_h, double* logdet_h, int* info_h, double terms_h[4]);
+
 /* ---- multi-GPU (nothing in the reference to mirror) ----
  * One process per GPU.  Rank 0 calls smn_comm_unique_id and ships the 128 bytes to the other
  * ranks by any host channel; every rank then calls smn_comm_init.  smn_allgather is an RCCL

@@ -76,6 +76,8 @@ PROTOTYPES = {
     "smn_spr_predict": [_vp, _i, _i, _i, _i, _d, _d, _d, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _d, _d,
                         _vp, _vp, _i64, _pd, _pd, _pi],
     "smn_comm_unique_id": [C.c_char_p],
+    "smn_lml_grad_terms": [_vp, _i, _i, _i, _i, _d, _d, _d, _vp, _i64, _i64, _vp, _vp, _i64, _vp, _d, _pd],
+    "smn_spr_loss_grad": [_vp, _i, _i, _i, _i, _d, _d, _d, _vp, _i64, _i64, _i64, _vp, _d, _d, _d, _pd, _pd, _pi, _pd],
     "smn_comm_init": [_vp, _i, _i, C.c_char_p],
     "smn_comm_destroy": [_vp],
     "smn_allgather": [_vp, _i, _vp, _vp, _i64],

@@ -2,7 +2,7 @@
 #include "internal.hpp"
 
 int smn_workspace(smn_ctx* ctx, int slot, size_t bytes, void** out) {
-  if (slot < 0 || slot >= 4) return smn_fail(ctx, SMN_EINVAL, "bad workspace slot");
+  if (slot < 0 || slot >= smn_ctx::kSlots) return smn_fail(ctx, SMN_EINVAL, "bad workspace slot");
   if (ctx->ws_bytes[slot] < bytes) {
     if (ctx->ws[slot]) {
       SMN_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -237,7 +237,7 @@ extern "C" int smn_ctx_destroy(smn_ctx* c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->comm) smn_comm_destroy(c);
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < smn_ctx::kSlots; ++i)
     if (c->ws[i]) (void)hipFree(c->ws[i]);
   for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
   if (c->d_scal) (void)hipFree(c->d_scal);

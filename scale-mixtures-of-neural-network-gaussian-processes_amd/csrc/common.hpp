@@ -20,8 +20,9 @@ struct smn_ctx {
   hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
   std::string err;
   // cached workspace arenas (grown on demand, freed with the context)
-  void* ws[4] = {nullptr, nullptr, nullptr, nullptr};
-  size_t ws_bytes[4] = {0, 0, 0, 0};
+  static constexpr int kSlots = 10;
+  void* ws[kSlots] = {};
+  size_t ws_bytes[kSlots] = {};
   // small device scalar block: [0..15] doubles scratch, ints after
   double* d_scal = nullptr;   // 64 doubles
   int* d_info = nullptr;      // 16 ints

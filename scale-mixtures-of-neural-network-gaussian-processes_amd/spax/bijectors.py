@@ -16,6 +16,10 @@ class PositiveBijector:
     def inverse(self, x):
         return self.base_inv(np.asarray(x, dtype=np.float64) - self.lower)
 
+    def grad(self, x):
+        """d constrained / d raw at raw value x (chain rule of the analytic hyper-parameter gradients)."""
+        return self.base_grad(np.asarray(x, dtype=np.float64))
+
 
 class Exp(PositiveBijector):
     def base(self, x):
@@ -23,6 +27,9 @@ class Exp(PositiveBijector):
 
     def base_inv(self, x):
         return np.log(x)
+
+    def base_grad(self, x):
+        return np.exp(x)
 
 
 class Softplus(PositiveBijector):
@@ -32,6 +39,9 @@ class Softplus(PositiveBijector):
     def base_inv(self, x):                       # spax/bijectors.py:53 — identity from 20 upwards
         x = np.asarray(x, dtype=np.float64)
         return np.where(x < 20.0, np.log(np.expm1(np.minimum(x, 20.0))), x)
+
+    def base_grad(self, x):                      # d softplus = sigmoid
+        return 0.5 * (1.0 + np.tanh(0.5 * x))
 
 
 _TYPES = {"exp": Exp, "softplus": Softplus}

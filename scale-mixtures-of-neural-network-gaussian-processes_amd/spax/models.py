@@ -56,6 +56,56 @@ class SPR(Module):
             log_prob = self.likelihood.prior_logpdf(self.y_host, cov)
         return -log_prob / self.num_data
 
+    def loss_and_grad(self):
+        """(loss, {variable name: d loss / d RAW value}) -- the analytic counterpart of
+        objax.GradValues(model.loss, model.vars()) in experiments/regression/train.py:61-67.
+        One augmented factorisation gives alpha = K~^-1 y, K~^-1, the quadratic form and logdet; one pass over
+        the lower triangle of X X^T / d contracts G = coef alpha alpha^T - K~^-1 with the forward-mode
+        dK/d(w_std, b_std, last_w_std) (csrc/grad.hip).  The (a, b) derivatives of the Student-t head and the
+        softplus chain rule are closed forms on the host.  MLP / dense-ResNet kernels only."""
+        import math
+        from .utils import digamma
+        kernel_fn = self.kernel.get_kernel_fn()
+        if not (isinstance(kernel_fn, KernelFn) and hasattr(self.likelihood, "lml_params")):
+            raise NotImplementedError("analytic gradients need an MLP / dense-ResNet KernelFn and a Gaussian or "
+                                      "Student-t likelihood; use train.value_and_grad_fd")
+        eps = self.eps.safe_value
+        df, scale = self.likelihood.lml_params()
+        x, ctx = self.x_data, self.x_data.ctx
+        net, act, L, w, b, lw = kernel_fn.params
+        n = self.num_data
+        quad, logdet, info = C.c_double(), C.c_double(), C.c_int()
+        terms = (C.c_double * 4)()
+        ctx.call("smn_spr_loss_grad", x.dcode, net, act, L, w, b, lw, x.ptr, n, x.shape[1], x.shape[1],
+                 self.y_data.ptr, eps, df, scale, C.byref(quad), C.byref(logdet), C.byref(info), terms)
+        names = {id(v): k for k, v in self.vars().items()}
+        nan = float("nan")
+        if info.value != 0:
+            return nan, {k: nan for k in self.vars()}
+        q, ld = quad.value, logdet.value
+        dlp = {}                                              # d logpdf / d constrained value
+        for var, t in ((self.kernel.w_std, terms[0]), (self.kernel.b_std, terms[1]),
+                       (self.kernel.last_w_std, terms[2]), (self.eps, terms[3])):
+            dlp[id(var)] = 0.5 * t
+        if df <= 0.0:                                         # likelihoods.py:25-28
+            lp = -0.5 * q - 0.5 * n * math.log(2.0 * math.pi) - 0.5 * ld
+        else:                                                 # likelihoods.py:45-50, utils.py:178-183
+            a_, b_ = self.likelihood.a.safe_value, self.likelihood.b.safe_value
+            t = 0.5 * (df + n)
+            qs = q / scale
+            lp = (-t * math.log1p(qs / df) - 0.5 * n * math.log(df * math.pi) + math.lgamma(t) - math.lgamma(0.5 * df)
+                  - 0.5 * (ld + n * math.log(scale)))
+            d_scale = t * qs / ((df + qs) * scale) - 0.5 * n / scale
+            d_df = (-0.5 * math.log1p(qs / df) + t * qs / (df * (df + qs)) - 0.5 * n / df
+                    + 0.5 * digamma(t) - 0.5 * digamma(0.5 * df))
+            dlp[id(self.likelihood.a)] = 2.0 * d_df - d_scale * b_ / (a_ * a_)     # df = 2a, scale = b/a
+            dlp[id(self.likelihood.b)] = d_scale / a_
+        grads = {}
+        for vid, g in dlp.items():
+            var = next(v for v in self.vars().values() if id(v) == vid)
+            grads[names[vid]] = float(-g / n * var.constraint.grad(var.value))
+        return -lp / n, grads
+
     # ---- spax/models.py:100-120
     def test_nll(self, x, y):
         eps = self.eps.safe_value

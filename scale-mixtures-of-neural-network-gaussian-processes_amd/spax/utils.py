@@ -63,3 +63,17 @@ def multivariate_t_logpdf(x, loc, shape, df, allow_singular=None):
     quad, logdet, _ = factor_stats(np.asarray(x, dtype=np.float64) - loc, shape)
     return (-t * math.log1p(quad / df) - n / 2 * math.log(df * math.pi) + math.lgamma(t) - math.lgamma(0.5 * df)
             - 0.5 * logdet)
+
+
+def digamma(x):
+    """psi(x) for x > 0: upward recurrence to x >= 10, then the asymptotic series (|error| < 1e-13)."""
+    x = float(x)
+    if not x > 0.0:
+        raise ValueError("digamma: x must be positive")
+    r = 0.0
+    while x < 10.0:
+        r -= 1.0 / x
+        x += 1.0
+    f = 1.0 / (x * x)
+    return r + math.log(x) - 0.5 / x - f * (1.0 / 12 - f * (1.0 / 120 - f * (1.0 / 252 - f * (1.0 / 240 - f / 132))))
+

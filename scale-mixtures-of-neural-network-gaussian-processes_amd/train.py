@@ -5,9 +5,10 @@ The model has at most six trainable scalars (w_std, b_std, last_w_std, eps and, 
 likelihood, a, b — the names experiments/regression/test.py:38-43 matches checkpoints by), all stored
 as softplus-inverse raw values (spax/base.py:15-25).  The gradient of the loss with respect to those raw
 values is taken by central differences: 2 loss evaluations (= 2 fused build + Cholesky passes on the GPU)
-per variable.  This is SURVEY.md section 8f.1's finite-difference fallback; the analytic form
-(1/2 tr((aa^T - K^-1) dK/dtheta) with forward-mode dK/dtheta through the fused recursion) is not built yet.
-Use float64 data: in float32 the loss carries ~1e-6 relative noise and the quotient is dominated by it.
+per variable.  This is SURVEY.md section 8f.1's finite-difference fallback (use float64 data: in float32 the loss
+carries ~1e-6 relative noise and the quotient is dominated by it).  The analytic form, 1/2 tr((c aa^T - K^-1)
+dK/dtheta) with forward-mode dK/dtheta through the layer recursion, is SPR.loss_and_grad (csrc/grad.hip);
+build_train_step prefers it when the model supports it.
 """
 from __future__ import annotations
 
@@ -17,12 +18,21 @@ import numpy as np
 
 from .spax.base import TrainVar
 
-__all__ = ["train_vars", "value_and_grad_fd", "Adam", "build_train_step"]
+__all__ = ["train_vars", "value_and_grad", "value_and_grad_fd", "Adam", "build_train_step"]
 
 
 def train_vars(model):
     """Dotted-name -> TrainVar for every trainable of the model (kernel, likelihood, eps)."""
     return {k: v for k, v in model.vars().items() if isinstance(v, TrainVar)}
+
+
+def value_and_grad(model, variables=None):
+    """(loss, {name: dloss/draw}) from the analytic gradient (SPR.loss_and_grad): ONE augmented factorisation
+    and one contraction pass instead of 2 loss evaluations per variable, and usable in float32."""
+    value, grads = model.loss_and_grad()
+    if variables is not None:
+        grads = {k: g for k, g in grads.items() if k in variables}
+    return value, grads
 
 
 def value_and_grad_fd(loss_fn, variables, h=1e-4):
@@ -61,13 +71,26 @@ class Adam:
             self.vars[k].assign(float(self.vars[k].value) - lr_t * self.m[k] / (math.sqrt(self.v[k]) + self.eps))
 
 
-def build_train_step(model, variables=None, optimizer=None, h=1e-4):
-    """train_step(learning_rate) -> loss before the update  (regression/train.py:61-67)."""
+def build_train_step(model, variables=None, optimizer=None, h=1e-4, method="auto"):
+    """train_step(learning_rate) -> loss before the update  (regression/train.py:61-67).
+    method: "analytic" (SPR.loss_and_grad), "fd" (central differences) or "auto" (analytic when the model's
+    kernel / likelihood support it, else finite differences)."""
+    if method not in ("auto", "analytic", "fd"):
+        raise ValueError("method must be 'auto', 'analytic' or 'fd'")
     variables = variables if variables is not None else train_vars(model)
     optimizer = optimizer or Adam(variables)
+    state = {"analytic": method != "fd" and hasattr(model, "loss_and_grad")}
 
     def train_step(learning_rate):
-        value, grads = value_and_grad_fd(model.loss, variables, h=h)
+        if state["analytic"]:
+            try:
+                value, grads = value_and_grad(model, variables)
+            except NotImplementedError:
+                if method == "analytic":
+                    raise
+                state["analytic"] = False
+        if not state["analytic"]:
+            value, grads = value_and_grad_fd(model.loss, variables, h=h)
         optimizer(learning_rate, grads)
         return value
 

@@ -78,3 +78,22 @@ def test_bijectors_and_trainvars():
     with pytest.raises(NotImplementedError):
         from smnngp.spax.bijectors import triangular
         triangular()
+
+
+def test_digamma_and_bijector_derivatives():
+    """Host pieces of the analytic gradient (SPR.loss_and_grad): psi against scipy, d constrained / d raw against
+    central differences."""
+    from scipy.special import digamma as ref
+    from smnngp.spax.bijectors import positive
+    from smnngp.spax.utils import digamma
+    for x in (0.05, 0.5, 1.0, 2.5, 9.99, 10.0, 123.4, 8200.5):
+        assert abs(digamma(x) - ref(x)) < 1e-12 * max(1.0, abs(ref(x)))
+    with pytest.raises(ValueError):
+        digamma(0.0)
+    for base in ("softplus", "exp"):
+        p = positive(base=base)
+        for raw in (-3.0, 0.0, 0.7, 25.0):
+            h = 1e-6
+            fd = (p(raw + h) - p(raw - h)) / (2 * h)
+            assert abs(p.grad(raw) - fd) < 1e-8 * max(1.0, abs(fd))
+

@@ -625,3 +625,75 @@ def test_restore_spr_from_a_reference_style_run_directory(tmp_path, method, netw
     for k, v in model.vars().items():
         assert float(model2.vars()[k].value) == float(v.value)
     assert model2.loss() == model.loss()
+
+
+# ----------------------------------------------------------------------------- analytic LML gradients
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("method", ["gp", "tp"])
+@pytest.mark.parametrize("network,act,nh", [("mlp", "relu", 2), ("mlp", "erf", 3), ("resnet", "relu", 2), ("resnet", "erf", 1)])
+def test_analytic_loss_gradient_matches_finite_differences_of_the_oracle(dtype, method, network, act, nh):
+    """SPR.loss_and_grad (one augmented factorisation + one contraction pass) against central differences of the
+    fp64 oracle loss, for every trainable of regression/train.py (w_std, b_std, last_w_std, eps, a, b)."""
+    from smnngp import nt_kernels
+    from smnngp.spax.kernels import NNGPKernel
+    from smnngp.spax.likelihoods import GaussianLikelihood, StudentTLikelihood
+    from smnngp.spax.models import SPR
+    rng = np.random.default_rng(17)
+    n, d = 150, 6
+    x = rng.standard_normal((n, d))
+    y = np.sin(x[:, 0]) + 0.3 * rng.standard_normal(n)
+    hyp = dict(w_std=1.3, b_std=0.4, last_w_std=0.9, eps=5e-2, alpha=1.7, beta=2.4)
+    base = nt_kernels.get_mlp_kernel if network == "mlp" else nt_kernels.get_dense_resnet_kernel
+
+    def get_kernel_fn(w_std, b_std, last_w_std):
+        return base(nh, 1, act=act, w_std=w_std, b_std=b_std, last_w_std=last_w_std)
+
+    kernel = NNGPKernel(get_kernel_fn, hyp["w_std"], hyp["b_std"], hyp["last_w_std"])
+    lik = GaussianLikelihood() if method == "gp" else StudentTLikelihood(hyp["alpha"], hyp["beta"])
+    model = SPR(kernel, lik, x.astype(dtype), y.astype(dtype), 0.0, 1.0, eps=hyp["eps"])
+    loss, grads = model.loss_and_grad()
+    okw = dict(kernel=network, num_hiddens=nh, act=act, method=method, **hyp)
+    keys = ("w_std", "b_std", "last_w_std", "eps") + (("alpha", "beta") if method == "tp" else ())
+    ref = O.spr_loss_grad_fd(x, y, keys=keys, **okw)
+    rl = O.spr_loss(x, y, **okw)
+    tol = 2e-6 if dtype == np.float64 else 1e-2
+    assert abs(loss - rl) < (1e-9 if dtype == np.float64 else 1e-3) * max(1.0, abs(rl))
+    assert abs(loss - model.loss()) < (1e-10 if dtype == np.float64 else 1e-4) * max(1.0, abs(rl))
+    vmap = {"w_std": kernel.w_std, "b_std": kernel.b_std, "last_w_std": kernel.last_w_std, "eps": model.eps}
+    if method == "tp":
+        vmap.update(alpha=lik.a, beta=lik.b)
+    names = {id(v): k for k, v in model.vars().items()}
+    assert set(grads) == set(model.vars())
+    scale = max(abs(v) for v in ref.values())
+    for k in keys:
+        var = vmap[k]
+        got = grads[names[id(var)]] / float(var.constraint.grad(var.value))     # undo the softplus chain rule
+        assert abs(got - ref[k]) < tol * max(scale, abs(ref[k])), (k, got, ref[k])
+
+
+def test_analytic_train_step_descends_and_agrees_with_fd_step():
+    """regression/train.py:61-67 with the analytic gradient: same first Adam update as finite differences."""
+    from smnngp import nt_kernels, train
+    from smnngp.spax.kernels import NNGPKernel
+    from smnngp.spax.likelihoods import StudentTLikelihood
+    from smnngp.spax.models import SPR
+    rng = np.random.default_rng(4)
+    n, d = 120, 4
+    x = rng.standard_normal((n, d)); y = np.tanh(x[:, 0] - x[:, 1]) + 0.2 * rng.standard_normal(n)
+
+    def make():
+        kernel = NNGPKernel(lambda w, b, l: nt_kernels.get_mlp_kernel(2, 1, act="relu", w_std=w, b_std=b, last_w_std=l),
+                            1.0, 1.0, 1.0)
+        return SPR(kernel, StudentTLikelihood(2.0, 2.0), x, y, 0.0, 1.0, eps=1e-1)
+
+    ma, mf = make(), make()
+    sa = train.build_train_step(ma, method="analytic")
+    sf = train.build_train_step(mf, method="fd", h=1e-5)
+    la, lf = sa(0.05), sf(0.05)
+    assert abs(la - lf) < 1e-10
+    for k, v in ma.vars().items():
+        assert abs(float(v.value) - float(mf.vars()[k].value)) < 1e-4
+    losses = [la] + [sa(0.05) for _ in range(15)]
+    assert losses[-1] < losses[0]
+    with pytest.raises(ValueError):
+        train.build_train_step(ma, method="bogus")
