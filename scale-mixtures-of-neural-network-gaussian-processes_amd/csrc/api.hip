@@ -217,7 +217,23 @@ extern "C" int smn_ctx_create(int device_id, smn_ctx** out) {
   }
   int prio_lo = 0, prio_hi = 0;   // the look-ahead stream carries the critical path: highest priority
   (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-  bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
+  // CU-masked streams (experiments): SMN_MAIN_MASK_CUS=n restricts the main stream to the first n mask bits;
+  // SMN_CHAIN_CUS=r gives the Cholesky a "bulk" stream that may not use the first r mask bits, so the panel
+  // chain on stream2 always finds r CUs the trailing update cannot occupy.
+  auto masked_stream = [&](hipStream_t* st, int lo, int hi) -> bool {
+    uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int b = lo; b < hi && b < 256; ++b) mask[b >> 5] |= 1u << (b & 31);
+    return hipExtStreamCreateWithCUMask(st, 8, mask) == hipSuccess;
+  };
+  bool main_ok;
+  if (const char* e = getenv("SMN_MAIN_MASK_CUS")) main_ok = masked_stream(&c->stream, 0, atoi(e));
+  else main_ok = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_hi) == hipSuccess;
+  if (const char* e = getenv("SMN_CHAIN_CUS")) c->chain_cus = atoi(e);
+  if (const char* e = getenv("SMN_CHAIN_MIN_N")) c->chain_min_n = atol(e);
+  if (c->chain_cus > 0 && c->chain_cus < c->num_cu) {
+    if (!masked_stream(&c->stream_bulk, c->chain_cus, c->num_cu)) c->stream_bulk = nullptr;   // no look-ahead then
+  }
+  bool ok = main_ok &&
             hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_hi) == hipSuccess &&
             hipEventCreateWithFlags(&c->ev_a, hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&c->ev_b, hipEventDisableTiming) == hipSuccess &&
@@ -248,6 +264,7 @@ extern "C" int smn_ctx_destroy(smn_ctx* c) {
   if (c->ev_t1) (void)hipEventDestroy(c->ev_t1);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
+  if (c->stream_bulk) (void)hipStreamDestroy(c->stream_bulk);
   delete c;
   return SMN_OK;
 }

@@ -19,6 +19,7 @@
 //                  front of the second sub-panel (K=128) and the trailing update (K=256, lower
 //                  tiles only), where nearly all the N^3/3 flops are.
 #include <climits>
+#include <type_traits>
 
 #include "gemm_nt.hpp"
 #include "internal.hpp"
@@ -45,10 +46,49 @@ struct PanelCfg<double> {
   static constexpr int THREADS = 192;
   static constexpr int LD = PB + 2;
 };
+// 16x16 MFMA tiles for the in-LDS block updates of the panel (operands read straight from the row-major LDS
+// image with one 16-byte read per lane; the K index is permuted identically for both operands).
+template <typename T>
+struct PanelMma;
+template <>
+struct PanelMma<float> {   // v_mfma_f32_16x16x4_f32: lane = (row | col) + 16 * k-group
+  static constexpr int TM = 16, ACC = 4, KSTEP = 16, NK = 4;
+  using acc_t = f32x4;
+  using vec_t = f32x4;
+  static __device__ __forceinline__ int frag_row(int lane) { return lane & 15; }
+  static __device__ __forceinline__ int frag_k(int lane) { return (lane >> 4) * 4; }
+  static __device__ __forceinline__ void mma1(acc_t& c, float a, float b) {
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ int acc_row(int lane, int i) { return 4 * (lane >> 4) + i; }
+  static __device__ __forceinline__ int acc_col(int lane) { return lane & 15; }
+};
+template <>
+struct PanelMma<double> {  // v_mfma_f64_16x16x4_f64
+  static constexpr int TM = 16, ACC = 4, KSTEP = 8, NK = 2;
+  using acc_t = f64x4;
+  using vec_t = f64x2;
+  static __device__ __forceinline__ int frag_row(int lane) { return lane & 15; }
+  static __device__ __forceinline__ int frag_k(int lane) { return (lane >> 4) * 2; }
+  static __device__ __forceinline__ void mma1(acc_t& c, double a, double b) {
+    c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ int acc_row(int lane, int i) { return (lane >> 4) + 4 * i; }
+  static __device__ __forceinline__ int acc_col(int lane) { return lane & 15; }
+};
+
 template <typename T>
 constexpr size_t panel_lds_bytes() {
   return sizeof(T) * ((size_t)(PB + PanelCfg<T>::XR) * PanelCfg<T>::LD + MP * MP + PB);
 }
+
+#ifdef SMN_PANEL_TIMING   // debug build only: phase times of workgroup 0 of the first panel, printed by the kernel
+#define PT_DECL long long pt_t = wall_clock64(), pt_acc[6] = {0, 0, 0, 0, 0, 0}
+#define PT_MARK(i) do { const long long n_ = wall_clock64(); pt_acc[i] += n_ - pt_t; pt_t = n_; } while (0)
+#else
+#define PT_DECL
+#define PT_MARK(i)
+#endif
 
 __device__ __forceinline__ float rsqrt_t(float x) { return __builtin_amdgcn_rsqf(x); }
 __device__ __forceinline__ double rsqrt_t(double x) { return 1.0 / sqrt(x); }
@@ -82,55 +122,104 @@ __global__ void __launch_bounds__(PanelCfg<T>::THREADS) panel_kernel(T* __restri
   const int tid = threadIdx.x;
   const int64_t rb = rbeg + (int64_t)blockIdx.x * XR;  // first appended row of this workgroup
   const int nx = (int)max((int64_t)0, min((int64_t)XR, n_total - rb));
-  // global -> LDS in 16-byte pieces, 8 loads in flight per thread (rows are 16-byte aligned on both sides)
+  // global -> LDS in 16-byte pieces (rows are 16-byte aligned on both sides).  SI loads per thread are in flight
+  // at once, and the first round of the appended rows is issued before the diagonal block's LDS writes.
   constexpr int RV = PB / VEC;  // vectors per row
-  auto stage_in = [&](int lrow0, int64_t grow0, int nrows) {
-    const int nvec = nrows * RV;
-    for (int base = 0; base < nvec; base += NT * 8) {
-      vec_t tmp[8];
+  constexpr int SI = 16;
+  PT_DECL;
+  auto gload = [&](vec_t (&tmp)[SI], int base, int nvec, int64_t grow0) {
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int idx = base + u * NT + tid;
-        if (idx < nvec) tmp[u] = *reinterpret_cast<const vec_t*>(&a[(grow0 + idx / RV) * lda + j0 + (idx % RV) * VEC]);
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int idx = base + u * NT + tid;
-        if (idx < nvec) *reinterpret_cast<vec_t*>(&S[(lrow0 + idx / RV) * LD + (idx % RV) * VEC]) = tmp[u];
-      }
+    for (int u = 0; u < SI; ++u) {
+      const int idx = base + u * NT + tid;
+      if (idx < nvec) tmp[u] = *reinterpret_cast<const vec_t*>(&a[(grow0 + idx / RV) * lda + j0 + (idx % RV) * VEC]);
     }
   };
-  stage_in(0, j0, PB);
-  stage_in(PB, rb, nx);
+  auto lstore = [&](const vec_t (&tmp)[SI], int base, int nvec, int lrow0) {
+#pragma unroll
+    for (int u = 0; u < SI; ++u) {
+      const int idx = base + u * NT + tid;
+      if (idx < nvec) *reinterpret_cast<vec_t*>(&S[(lrow0 + idx / RV) * LD + (idx % RV) * VEC]) = tmp[u];
+    }
+  };
+  {
+    const int nd = PB * RV, nxv = nx * RV;
+    vec_t ta[SI], tb[SI];
+    gload(tb, 0, nxv, rb);
+    for (int base = 0; base < nd; base += NT * SI) {
+      gload(ta, base, nd, j0);
+      lstore(ta, base, nd, 0);
+    }
+    lstore(tb, 0, nxv, PB);
+    for (int base = NT * SI; base < nxv; base += NT * SI) {
+      gload(tb, base, nxv, rb);
+      lstore(tb, base, nxv, PB);
+    }
+  }
   __syncthreads();
+  PT_MARK(0);
 
   const int row = tid;
   const bool active = row < PB + nx && !(prefactored && row < PB);
-  using M = Mfma<T>;
-  constexpr int CB = 32;                               // column block brought up to date on the MFMA
+  using M = PanelMma<T>;
+  constexpr int CB = 16;                               // column block brought up to date on the MFMA
   constexpr int NW = NT / 64;                          // waves
-  constexpr int RT = (PB + XR) / M::TM, CT = CB / M::TN;
+  constexpr int RT = (PB + XR) / M::TM;                // 16-row tiles of the LDS image
+  constexpr int TPW = (RT + NW - 1) / NW;              // row tiles per wave: independent accumulators, one B fragment
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int fr = M::frag_row(lane), fk = M::frag_chunk(lane, 0) * VEC;   // fragment row / k offset in an 8-k group
+  const int fr = M::frag_row(lane), fk = M::frag_k(lane);
   for (int c0 = 0; c0 < PB; c0 += MP) {
-    const int cb = c0 & ~(CB - 1);                     // first column of the current 32-column block
+    const int cb = c0 & ~(CB - 1);                     // first column of the current 16-column block
     if (c0 == cb && cb > 0) {
-      // S[rows >= rmin, cb:cb+32] -= S[rows, 0:cb] * S[cb:cb+32, 0:cb]^T   (MFMA, operands straight from S)
+      // S[rows >= rmin, cb:cb+16] -= S[rows, 0:cb] * S[cb:cb+16, 0:cb]^T   (MFMA, operands straight from S)
       const int rmin = prefactored ? PB : cb;
-      for (int p = wave; p < RT * CT; p += NW) {
-        const int rt = (p / CT) * M::TM, ct = cb + (p % CT) * M::TN;
-        if (rt < rmin) continue;
-        typename M::acc_t acc;
+      // Tiles wholly above rmin are finished rows: wave w skips its first u0 tiles.  The skip count is wave-uniform
+      // and fixed for the whole K loop, so each count gets its own straight-line instantiation (no branches
+      // between the MFMAs, accumulators stay in place).
+      static_assert(RT % NW == 0, "every wave owns the same number of 16-row tiles");
+      const int first = rmin / M::TM;                                   // first tile that still needs the update
+      const int u0 = first <= wave ? 0 : (first - wave + NW - 1) / NW;  // tiles of this wave to skip
+      auto block_update = [&](auto u0c) {
+        constexpr int U0 = decltype(u0c)::value;
+        if constexpr (U0 < TPW) {
+          typename M::acc_t acc[TPW];
 #pragma unroll
-        for (int i = 0; i < M::ACC; ++i) acc[i] = -S[(rt + M::acc_row(lane, i)) * LD + ct + M::acc_col(lane)];
-        const T* pa = &S[(rt + fr) * LD + fk];
-        const T* pb = &S[(ct + fr) * LD + fk];
-        for (int kb = 0; kb < cb; kb += 8)
-          M::mma(acc, *reinterpret_cast<const vec_t*>(pa + kb), *reinterpret_cast<const vec_t*>(pb + kb));
+          for (int u = U0; u < TPW; ++u) {
+            const int rt = (wave + u * NW) * M::TM;
 #pragma unroll
-        for (int i = 0; i < M::ACC; ++i) S[(rt + M::acc_row(lane, i)) * LD + ct + M::acc_col(lane)] = -acc[i];
+            for (int i = 0; i < M::ACC; ++i) acc[u][i] = -S[(rt + M::acc_row(lane, i)) * LD + cb + M::acc_col(lane)];
+          }
+          const T* pb = &S[(cb + fr) * LD + fk];
+          const T* pa = &S[(wave * M::TM + fr) * LD + fk];
+          for (int kb = 0; kb < cb; kb += M::KSTEP) {
+            const typename M::vec_t bv = *reinterpret_cast<const typename M::vec_t*>(pb + kb);
+            typename M::vec_t av[TPW];
+#pragma unroll
+            for (int u = U0; u < TPW; ++u)
+              av[u] = *reinterpret_cast<const typename M::vec_t*>(pa + u * NW * M::TM * LD + kb);
+            // k-slice outer, tile inner: consecutive MFMAs hit different accumulators
+#pragma unroll
+            for (int i = 0; i < M::NK; ++i)
+#pragma unroll
+              for (int u = U0; u < TPW; ++u) M::mma1(acc[u], av[u][i], bv[i]);
+          }
+#pragma unroll
+          for (int u = U0; u < TPW; ++u) {
+            const int rt = (wave + u * NW) * M::TM;
+#pragma unroll
+            for (int i = 0; i < M::ACC; ++i) S[(rt + M::acc_row(lane, i)) * LD + cb + M::acc_col(lane)] = -acc[u][i];
+          }
+        }
+      };
+      static_assert(TPW <= 4, "dispatch below covers up to 4 tiles per wave");
+      switch (u0) {
+        case 0: block_update(std::integral_constant<int, 0>{}); break;
+        case 1: block_update(std::integral_constant<int, 1>{}); break;
+        case 2: block_update(std::integral_constant<int, 2>{}); break;
+        case 3: block_update(std::integral_constant<int, 3>{}); break;
+        default: break;
       }
       __syncthreads();
+      PT_MARK(1);
     }
     const bool work = active && row >= c0;
     T v[MP];
@@ -156,6 +245,7 @@ __global__ void __launch_bounds__(PanelCfg<T>::THREADS) panel_kernel(T* __restri
       }
     }
     __syncthreads();
+    PT_MARK(2);
     if (work) {
       T lm[MP][MP], rinv[MP];
 #pragma unroll
@@ -195,6 +285,7 @@ __global__ void __launch_bounds__(PanelCfg<T>::THREADS) panel_kernel(T* __restri
       }
     }
     __syncthreads();
+    PT_MARK(3);
   }
 
   if (blockIdx.x == 0 && !prefactored) {
@@ -225,6 +316,13 @@ __global__ void __launch_bounds__(PanelCfg<T>::THREADS) panel_kernel(T* __restri
     const int r = idx / RV, c = (idx % RV) * VEC;
     *reinterpret_cast<vec_t*>(&a[(rb + r) * lda + j0 + c]) = *reinterpret_cast<const vec_t*>(&S[(PB + r) * LD + c]);
   }
+#ifdef SMN_PANEL_TIMING
+  __syncthreads();
+  PT_MARK(4);
+  if (tid == 0 && j0 == 0 && (blockIdx.x == 0 || blockIdx.x == 5))
+    printf("panel wg%d (100 MHz ticks): stage_in %lld  mfma_blocks %lld  dots %lld  factor+solve %lld  store %lld\n",
+           (int)blockIdx.x, pt_acc[0], pt_acc[1], pt_acc[2], pt_acc[3], pt_acc[4]);
+#endif
 }
 
 // Lower triangles of ALL factored diagonal blocks: side buffer -> matrix, once, after the last panel
@@ -553,6 +651,8 @@ int cholesky_t(smn_ctx* ctx, T* a, int64_t n_total, int64_t n_factor, int64_t ld
   // columns instead of once per 256.
   const int64_t S = ctx->super_panel / W * W;
   if (!la && S > W) {
+    hipStream_t sb = n_total >= ctx->chain_min_n ? ctx->stream_bulk : nullptr;   // look-ahead across super-panels
+    bool bulk_busy = false;
     for (int64_t s0 = 0; s0 < n_factor; s0 += S) {
       const int64_t s_end = (n_factor - s0 < S) ? n_factor : s0 + S;
       for (int64_t j0 = s0; j0 < s_end; j0 += W) {
@@ -566,11 +666,31 @@ int cholesky_t(smn_ctx* ctx, T* a, int64_t n_total, int64_t n_factor, int64_t ld
         if (j1 < s_end)   // near update: columns [j1, s_end), all rows from the diagonal down
           SMN_TRY(launch_update<T>(ctx, st, a, lda, j1, j1, j0, (int)w, (n_total - j1) / kTile, (s_end - j1) / kTile, 2));
       }
-      if (s_end < n_total) {   // far update: K = s_end - s0
+      if (s_end < n_total && !sb) {   // far update: K = s_end - s0
         const int64_t tm = (n_total - s_end) / kTile;
         SMN_TRY(launch_update<T>(ctx, st, a, lda, s_end, s_end, s0, (int)(s_end - s0), tm, tm, 1));
+      } else if (s_end < n_total) {
+        // Look-ahead across super-panels (SMN_CHAIN_CUS): the far update is split by tile column into F0 (the
+        // NEXT super-panel's columns; stays on this stream, the chain needs it) and F1 (everything beyond; goes
+        // to the CU-masked bulk stream and runs beside the next super-panel's panel chain, which always finds
+        // the reserved CUs free).  F1 launches are serial on the bulk stream; F0(s) writes tiles F1(s-1) also
+        // writes, so it waits for it; F1(s) and the chain of s+1 touch disjoint columns.
+        const int64_t s_next = s_end >= n_factor ? s_end : ((n_factor - s_end < S) ? n_factor : s_end + S);
+        SMN_HIP(ctx, hipEventRecord(ctx->ev_a, st));
+        SMN_HIP(ctx, hipStreamWaitEvent(sb, ctx->ev_a, 0));
+        if (bulk_busy) SMN_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_b, 0));
+        if (s_next > s_end)
+          SMN_TRY(launch_update<T>(ctx, st, a, lda, s_end, s_end, s0, (int)(s_end - s0), (n_total - s_end) / kTile,
+                                   (s_next - s_end) / kTile, 2));
+        if (n_total > s_next) {
+          const int64_t tm = (n_total - s_next) / kTile;
+          SMN_TRY(launch_update<T>(ctx, sb, a, lda, s_next, s_next, s0, (int)(s_end - s0), tm, tm, 1));
+          SMN_HIP(ctx, hipEventRecord(ctx->ev_b, sb));
+          bulk_busy = true;
+        }
       }
     }
+    if (bulk_busy) SMN_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_b, 0));
     if (keep_factor) {
       hipLaunchKernelGGL(copy_diag_kernel<T>, dim3((unsigned)(n_factor / PB)), dim3(1024), 0, st, a, lda,
                          static_cast<const T*>(side));
@@ -579,9 +699,13 @@ int cholesky_t(smn_ctx* ctx, T* a, int64_t n_total, int64_t n_factor, int64_t ld
     return SMN_OK;
   }
   hipStream_t s2 = la ? ctx->stream2 : st;
+  // with SMN_CHAIN_CUS the updates of the look-ahead schedule go to the CU-masked bulk stream, so the panel
+  // chain on stream2 always finds the reserved CUs free
+  hipStream_t su = (la && ctx->stream_bulk) ? ctx->stream_bulk : st;
   if (la) {
     SMN_HIP(ctx, hipEventRecord(ctx->ev_a, st));
     SMN_HIP(ctx, hipStreamWaitEvent(s2, ctx->ev_a, 0));
+    if (su != st) SMN_HIP(ctx, hipStreamWaitEvent(su, ctx->ev_a, 0));
   }
   for (int64_t j0 = 0; j0 < n_factor; j0 += W) {
     const int64_t w = (n_factor - j0 < W) ? n_factor - j0 : W;
@@ -592,22 +716,30 @@ int cholesky_t(smn_ctx* ctx, T* a, int64_t n_total, int64_t n_factor, int64_t ld
     }
     if (la) {
       SMN_HIP(ctx, hipEventRecord(ctx->ev_b, s2));
-      SMN_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_b, 0));
+      SMN_HIP(ctx, hipStreamWaitEvent(su, ctx->ev_b, 0));
     }
     const int64_t j1 = j0 + w;
     if (j1 >= n_total) break;
     const int64_t tm = (n_total - j1) / kTile;
     if (la && j1 < n_factor && tm > 2) {
-      SMN_TRY(launch_update<T>(ctx, st, a, lda, j1, j1, j0, (int)w, tm, 2, 0, 1));   // T0
-      SMN_HIP(ctx, hipEventRecord(ctx->ev_a, st));
+      SMN_TRY(launch_update<T>(ctx, su, a, lda, j1, j1, j0, (int)w, tm, 2, 0, 1));   // T0
+      SMN_HIP(ctx, hipEventRecord(ctx->ev_a, su));
       SMN_HIP(ctx, hipStreamWaitEvent(s2, ctx->ev_a, 0));
-      SMN_TRY(launch_update<T>(ctx, st, a, lda, j1 + W, j1 + W, j0, (int)w, tm - 2, tm - 2, 1));
+      SMN_TRY(launch_update<T>(ctx, su, a, lda, j1 + W, j1 + W, j0, (int)w, tm - 2, tm - 2, 1));
     } else {
-      SMN_TRY(launch_update<T>(ctx, st, a, lda, j1, j1, j0, (int)w, tm, tm, 1));
+      SMN_TRY(launch_update<T>(ctx, su, a, lda, j1, j1, j0, (int)w, tm, tm, 1));
       if (la) {
-        SMN_HIP(ctx, hipEventRecord(ctx->ev_a, st));
+        SMN_HIP(ctx, hipEventRecord(ctx->ev_a, su));
         SMN_HIP(ctx, hipStreamWaitEvent(s2, ctx->ev_a, 0));
       }
+    }
+  }
+  if (la) {   // the caller's stream continues after both helper streams
+    SMN_HIP(ctx, hipEventRecord(ctx->ev_b, s2));
+    SMN_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_b, 0));
+    if (su != st) {
+      SMN_HIP(ctx, hipEventRecord(ctx->ev_a, su));
+      SMN_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_a, 0));
     }
   }
   if (keep_factor) {

@@ -15,8 +15,11 @@
 
 struct smn_ctx {
   int device = 0;
-  hipStream_t stream = nullptr;   // main stream: every public call is ordered on it
+  hipStream_t stream = nullptr;   // main stream (high priority): every public call is ordered on it
   hipStream_t stream2 = nullptr;  // look-ahead stream of the Cholesky driver
+  hipStream_t stream_bulk = nullptr;  // CU-masked stream of the far updates: may not use the first chain_cus CUs
+  int chain_cus = 32;                 // CUs kept free for the panel chain (env SMN_CHAIN_CUS; 0 = no look-ahead)
+  int64_t chain_min_n = 8192;         // look-ahead only from this matrix size on (env SMN_CHAIN_MIN_N)
   hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
   std::string err;
   // cached workspace arenas (grown on demand, freed with the context)
