@@ -59,9 +59,12 @@ int smn_memcpy2d_d2h(smn_ctx* ctx, void* dst_h, size_t dpitch, const void* src_d
 /* timing hooks (hipEvents on the context's stream) */
 int smn_timer_start(smn_ctx* ctx);
 int smn_timer_stop_ms(smn_ctx* ctx, double* ms);           /* synchronises */
-/* per-kernel timing: while enabled every kernel launch is bracketed by a hipEvent pair on its own
+/* per-kernel timing: while enabled kernel launches are bracketed by a hipEvent pair on their own
  * stream.  category: 0 prep (pad/tables), 1 fused Gram+recursion build, 2 stand-alone recursion,
- * 3 Cholesky panel, 4 Cholesky strip update, 5 Cholesky trailing update, 6 other. */
+ * 3 Cholesky panel, 4 Cholesky strip update, 5 Cholesky trailing update, 6 other.
+ * on: 0 off; 1 every category; (2 << c) only category c (values add up to a mask).  An event pair
+ * costs a few microseconds of queue time per launch, so timing ONE category perturbs a step far less
+ * than timing all ~280 launches of it. */
 int smn_profile_enable(smn_ctx* ctx, int on);
 int smn_profile_read(smn_ctx* ctx, int category, double* total_ms, int* launches);
 

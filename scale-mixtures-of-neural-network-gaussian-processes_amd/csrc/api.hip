@@ -360,6 +360,7 @@ extern "C" int smn_profile_enable(smn_ctx* ctx, int on) {
   if (!ctx) return SMN_EINVAL;
   SMN_HIP(ctx, hipStreamSynchronize(ctx->stream));
   ctx->prof = on != 0;
+  ctx->prof_mask = on == 1 ? ~0u : ((unsigned)on >> 1);   // 1: every category; 2 << c: category c only (masks add)
   ctx->prof_used = 0;
   ctx->prof_cat.clear();
   return SMN_OK;

@@ -33,6 +33,7 @@ struct smn_ctx {
   int nranks = 1, rank = 0;
   // per-kernel timing (smn_profile_*): hipEvent pairs around launches, resolved on read
   bool prof = false;
+  unsigned prof_mask = ~0u;          // categories that get event pairs (smn_profile_enable)
   std::vector<hipEvent_t> prof_ev;   // pool, used pairwise
   std::vector<int> prof_cat;         // category of pair i
   size_t prof_used = 0;              // events handed out
@@ -51,7 +52,8 @@ enum { PROF_PREP = 0, PROF_BUILD = 1, PROF_RECURSION = 2, PROF_PANEL = 3, PROF_S
 // Brackets the launches issued during its lifetime with an event pair when profiling is on.
 struct ProfScope {
   smn_ctx* c; hipStream_t st; bool on;
-  ProfScope(smn_ctx* ctx, int cat, hipStream_t stream) : c(ctx), st(stream), on(ctx->prof) {
+  ProfScope(smn_ctx* ctx, int cat, hipStream_t stream)
+      : c(ctx), st(stream), on(ctx->prof && ((ctx->prof_mask >> cat) & 1u)) {
     if (!on) return;
     if (c->prof_used + 2 > c->prof_ev.size()) {
       for (int i = 0; i < 256; ++i) {
