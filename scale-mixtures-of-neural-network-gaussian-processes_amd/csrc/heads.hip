@@ -175,7 +175,9 @@ extern "C" int smn_lml(smn_ctx* ctx, int dtype, void* k_d, int64_t n, int64_t ld
   if (df > 0.0 && !(scale > 0.0)) return smn_fail(ctx, SMN_EINVAL, "smn_lml: scale must be > 0");
   Aug g;
   SMN_TRY(aug_alloc(ctx, dtype, n, 0, 1, &g));
-  SMN_HIP(ctx, hipMemsetAsync(g.a, 0, g.es * (size_t)g.n_total * (size_t)g.n_total, ctx->stream));
+  // only rows >= n (identity padding + appended rows) need clearing: above them just the lower triangle is ever
+  // read (tests: test_cholesky_reads_the_lower_triangle_only), and that is copied in below
+  SMN_HIP(ctx, hipMemsetAsync(g.at(n, 0), 0, g.es * (size_t)(g.n_total - n) * (size_t)g.lda, ctx->stream));
   SMN_TRY(copy_matrix(ctx, dtype, g.a, g.lda, k_d, ldk, n, n, 1));
   SMN_TRY(fill_identity_pad(ctx, dtype, g.a, g.lda, g.n_pad, n));
   double quad = 0.0, ld = 0.0;
@@ -197,7 +199,7 @@ extern "C" int smn_predict(smn_ctx* ctx, int dtype, void* kj_d, int64_t n, int64
   Aug g;
   SMN_TRY(aug_alloc(ctx, dtype, n, t, c, &g));
   const char* kb = static_cast<const char*>(kj_d);
-  SMN_HIP(ctx, hipMemsetAsync(g.a, 0, g.es * (size_t)g.n_total * (size_t)g.n_total, ctx->stream));
+  SMN_HIP(ctx, hipMemsetAsync(g.at(n, 0), 0, g.es * (size_t)(g.n_total - n) * (size_t)g.lda, ctx->stream));
   SMN_TRY(copy_matrix(ctx, dtype, g.a, g.lda, kb, ldk, n, n, 1));
   SMN_TRY(copy_matrix(ctx, dtype, g.at(g.n_pad, 0), g.lda, kb + g.es * (size_t)(n * ldk), ldk, t, n, 0));
   SMN_TRY(copy_matrix(ctx, dtype, g.at(g.n_pad, g.n_pad), g.lda, kb + g.es * (size_t)(n * ldk + n), ldk, t, t, 1));

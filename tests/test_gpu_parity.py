@@ -345,6 +345,31 @@ def test_cholesky_and_schur(L, ctx, dtype, n, m):
         assert relerr(np.tril(got[n:, n:]), np.tril(s)) < tol
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("n,m", [(1024, 0), (896, 128), (9216, 0)])
+def test_cholesky_reads_the_lower_triangle_only(L, ctx, dtype, n, m):
+    """LAPACK 'L' semantics: whatever sits strictly above the diagonal (here NaN) must not reach the factor, the
+    solved rows, the Schur complement or logdet.  Sizes are tile multiples so the matrix is factored in place."""
+    rng = np.random.default_rng(n + m + 1)
+    if n + m > 4096:                                                         # cheap SPD matrix for the large case
+        a = rng.standard_normal((n + m, 64)); a = a @ a.T / 64 + np.eye(n + m)
+    else:
+        a = _spd(rng, n + m, np.float64)
+    poisoned = a.copy()
+    poisoned[np.triu_indices(n + m, 1)] = np.nan
+    info, logdet = C.c_int(), C.c_double()
+    ad = ctx.to_device(poisoned.astype(dtype))
+    ctx.call("smn_cholesky", L.dtype_code(dtype), ad.ptr, n + m, n, n + m, 0, 0.0, 0.0, C.byref(info), C.byref(logdet))
+    got = ad.numpy().astype(np.float64)
+    ref = ctx.to_device(a.astype(dtype))
+    info2, logdet2 = C.c_int(), C.c_double()
+    ctx.call("smn_cholesky", L.dtype_code(dtype), ref.ptr, n + m, n, n + m, 0, 0.0, 0.0, C.byref(info2), C.byref(logdet2))
+    want = ref.numpy().astype(np.float64)
+    il = np.tril_indices(n + m)
+    assert info.value == 0 and info2.value == 0 and logdet.value == logdet2.value
+    assert np.isfinite(got[il]).all() and (got[il] == want[il]).all()        # bit-identical lower triangle
+
+
 @pytest.mark.parametrize("dtype,n,m", [(np.float64, 6144, 128), (np.float32, 8192, 0)])
 def test_cholesky_more_workgroups_than_cus_and_lookahead(L, ctx, dtype, n, m):
     """Sizes where a panel launch has more workgroups than the chip has CUs (f64: 16 rows per workgroup)
