@@ -1,0 +1,237 @@
+"""BASELINE.json's configurations at FULL size on the GPU, checked through what does not need an N x N oracle:
+sampled entries against the fp64 oracle evaluated on just those rows, closed-form diagonals, exact symmetry,
+homogeneity, reconstruction of the factor on sampled entries, agreement between the fused / unfused / sharded
+routes, permutation invariance of the log-marginal likelihood.  (C2 is small enough for a direct oracle run.)
+
+Tolerances are the north-star's: 1e-2 relative in fp32 (asserted tighter where the arithmetic allows), 1e-5 in fp64.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import nngp_oracle as O  # noqa: E402  (test infrastructure only)
+
+
+@pytest.fixture(scope="module")
+def L():
+    from smnngp import _lib
+    return _lib
+
+
+@pytest.fixture(scope="module")
+def ctx(L):
+    return L.default_context()
+
+
+def relerr(a, b):
+    a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+    return np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300)
+
+
+def fetch_rows(L, ctx, arr, rows, ncols, ld, dtype):
+    """Rows `rows` of a device matrix (only these cross PCIe)."""
+    out = np.empty((len(rows), ncols), dtype)
+    es = np.dtype(dtype).itemsize
+    for k, r in enumerate(rows):
+        ctx.call("smn_memcpy_d2h", out[k].ctypes.data_as(C.c_void_p), C.c_void_p(arr.ptr.value + int(r) * ld * es), ncols * es)
+    return out
+
+
+# ----------------------------------------------------------------------------- C4: N=16384 d=3072 L=4 ReLU fp32
+@pytest.fixture(scope="module")
+def c4(L, ctx):
+    n, d = 16384, 3072
+    rng = np.random.default_rng(0)
+    xh = rng.standard_normal((n, d)).astype(np.float32)
+    yh = rng.standard_normal(n).astype(np.float32)
+    return dict(n=n, d=d, xh=xh, yh=yh, x=ctx.to_device(xh), y=ctx.to_device(yh))
+
+
+def test_c4_kernel_sampled_entries_diagonal_symmetry_and_homogeneity(L, ctx, c4):
+    n, d, x = c4["n"], c4["d"], c4["x"]
+    k = ctx.empty((n, n), np.float32)
+    ctx.call("smn_kernel_mlp", L.F32, L.NET_MLP, L.ACT["relu"], 4, 1.0, 1e-8, 1.0, x.ptr, n, d, None, 0, 0, d,
+             L.GET_NNGP, L.FILL_FULL, k.ptr, None, n)
+    rng = np.random.default_rng(1)
+    rows = np.sort(rng.choice(n, 48, replace=False)); cols = np.sort(rng.choice(n, 64, replace=False))
+    got = fetch_rows(L, ctx, k, rows, n, n, np.float32)
+    x64 = c4["xh"].astype(np.float64)
+    ref = O.mlp_kernel(x64[rows], x64[cols], 4, "relu", 1.0, 1e-8, 1.0)
+    assert relerr(got[:, cols], ref) < 2e-3
+    # closed-form diagonal on the sampled rows
+    dg = O.diag_recursion((x64[rows] ** 2).sum(1) / d, 4, "relu", 1.0, 1e-8, 1.0)
+    assert relerr(got[np.arange(len(rows)), rows], dg) < 1e-5
+    # exact symmetry: K[rows, cols] == K[cols, rows]^T bit for bit (the upper triangle is a mirrored store)
+    got_t = fetch_rows(L, ctx, k, cols, n, n, np.float32)
+    assert (got[:, cols] == got_t[:, rows].T).all()
+    # ReLU NNGP with b = 0 is 2-homogeneous: K(2X) = 4 K(X); powers of two commute with every rounding on the way
+    x2 = ctx.to_device(c4["xh"] * np.float32(2.0))
+    k0 = ctx.empty((n, n), np.float32); k2 = ctx.empty((n, n), np.float32)
+    for xx, kk in ((x, k0), (x2, k2)):
+        ctx.call("smn_kernel_mlp", L.F32, L.NET_MLP, L.ACT["relu"], 4, 1.0, 0.0, 1.0, xx.ptr, n, d, None, 0, 0, d,
+                 L.GET_NNGP, L.FILL_LOWER, kk.ptr, None, n)
+    a = fetch_rows(L, ctx, k0, rows, n, n, np.float32); b = fetch_rows(L, ctx, k2, rows, n, n, np.float32)
+    for i, r in enumerate(rows):
+        assert relerr(b[i, : r + 1], 4.0 * a[i, : r + 1].astype(np.float64)) < 1e-6
+
+
+def test_c4_factor_reconstructs_sampled_entries_and_logdet(L, ctx, c4):
+    n, d, x = c4["n"], c4["d"], c4["x"]
+    eps = 1e-3
+    a = ctx.empty((n, n), np.float32)
+    ctx.call("smn_kernel_mlp", L.F32, L.NET_MLP, L.ACT["relu"], 4, 1.0, 1e-8, 1.0, x.ptr, n, d, None, 0, 0, d,
+             L.GET_NNGP, L.FILL_LOWER, a.ptr, None, n)
+    rng = np.random.default_rng(2)
+    rows = np.sort(rng.choice(n, 40, replace=False))
+    before = fetch_rows(L, ctx, a, rows, n, n, np.float32).astype(np.float64)
+    info, logdet = C.c_int(), C.c_double()
+    ctx.call("smn_cholesky", L.F32, a.ptr, n, n, n, n, eps, 0.0, C.byref(info), C.byref(logdet))
+    assert info.value == 0
+    lrows = fetch_rows(L, ctx, a, rows, n, n, np.float32).astype(np.float64)
+    for i, r in enumerate(rows):                       # zero the (unspecified) part right of the diagonal
+        lrows[i, r + 1:] = 0.0
+    # (L L^T)[r, c] for sampled r >= c in the sample
+    for i, r in enumerate(rows):
+        for j, c in enumerate(rows[: i + 1]):
+            want = before[i, c] + (eps if r == c else 0.0)
+            got = float(lrows[i, : c + 1] @ lrows[j, : c + 1])
+            assert abs(got - want) < 2e-4 * max(1.0, abs(want)), (r, c, got, want)
+    # logdet = 2 sum log L_ii : check on the full diagonal
+    diag = np.empty(n, np.float32)
+    ctx.call("smn_memcpy2d_d2h", diag.ctypes.data_as(C.c_void_p), 4, a.ptr, (n + 1) * 4, 4, n)   # pitch n+1: the diagonal
+    assert abs(logdet.value - 2.0 * np.log(diag.astype(np.float64)).sum()) < 1e-6 * abs(logdet.value)
+
+
+def test_c4_fused_unfused_and_sharded_routes_and_permutation_invariance(L, ctx, c4):
+    from smnngp import sharding as S
+    n, d, x, y = c4["n"], c4["d"], c4["x"], c4["y"]
+    eps = 1e-3
+    lp, quad, logdet, info = C.c_double(), C.c_double(), C.c_double(), C.c_int()
+    ctx.call("smn_spr_loss", L.F32, L.NET_MLP, L.ACT["relu"], 4, 1.0, 1e-8, 1.0, x.ptr, n, d, d, y.ptr, eps, 0.0, 1.0,
+             C.byref(lp), C.byref(quad), C.byref(logdet), C.byref(info))
+    fused = (lp.value, quad.value, logdet.value)
+    assert info.value == 0 and np.isfinite(fused).all()
+    assert abs(fused[0] - (-0.5 * fused[1] - 0.5 * n * np.log(2 * np.pi) - 0.5 * fused[2])) < 1e-9 * abs(fused[0])
+    # Student-t head from the same (quad, logdet): spax/utils.py:178-183
+    df, scale = 4.0, 1.5
+    ctx.call("smn_spr_loss", L.F32, L.NET_MLP, L.ACT["relu"], 4, 1.0, 1e-8, 1.0, x.ptr, n, d, d, y.ptr, eps, df, scale,
+             C.byref(lp), C.byref(quad), C.byref(logdet), C.byref(info))
+    import math
+    t = 0.5 * (df + n)
+    want_t = (-t * math.log1p(fused[1] / scale / df) - 0.5 * n * math.log(df * math.pi) + math.lgamma(t) - math.lgamma(0.5 * df)
+              - 0.5 * (fused[2] + n * math.log(scale)))
+    assert quad.value == fused[1] and logdet.value == fused[2] and abs(lp.value - want_t) < 1e-9 * abs(want_t)
+    # 8 ranks played on one GPU: paired lower-block shards -> unpack -> smn_lml
+    world = 8
+    chunk, h = S.paired_chunk_elems(n, world), S.block_rows(n, world)
+    stage = ctx.empty((world * chunk,), np.float32); k = ctx.empty((n, n), np.float32)
+    for r in range(world):
+        ctx.call("smn_kernel_mlp_shard", L.F32, L.NET_MLP, L.ACT["relu"], 4, 1.0, 1e-8, 1.0, x.ptr, n, d, d, world, r, h,
+                 L.GET_NNGP, C.c_void_p(stage.ptr.value + r * chunk * 4), None)
+    ctx.call("smn_unpack_lower_blocks", L.F32, stage.ptr, n, world, h, k.ptr, n)
+    ctx.call("smn_lml", L.F32, k.ptr, n, n, y.ptr, eps, 0.0, 1.0, C.byref(lp), C.byref(quad), C.byref(logdet), C.byref(info))
+    assert info.value == 0
+    assert abs(lp.value - fused[0]) < 1e-6 * abs(fused[0]) and abs(logdet.value - fused[2]) < 1e-6 * abs(fused[2])
+    # the LML does not depend on the order of the data points
+    perm = np.random.default_rng(3).permutation(n)
+    xp = ctx.to_device(c4["xh"][perm]); yp = ctx.to_device(c4["yh"][perm])
+    ctx.call("smn_spr_loss", L.F32, L.NET_MLP, L.ACT["relu"], 4, 1.0, 1e-8, 1.0, xp.ptr, n, d, d, yp.ptr, eps, 0.0, 1.0,
+             C.byref(lp), C.byref(quad), C.byref(logdet), C.byref(info))
+    assert info.value == 0
+    assert abs(lp.value - fused[0]) < 1e-4 * abs(fused[0]) and abs(logdet.value - fused[2]) < 1e-4 * abs(fused[2])
+
+
+# ----------------------------------------------------------------------------- C2: N=4096 d=512 L=3 ReLU fp32 (direct oracle)
+def test_c2_gp_regression_against_the_oracle():
+    from smnngp import nt_kernels
+    from smnngp.spax.kernels import NNGPKernel
+    from smnngp.spax.likelihoods import GaussianLikelihood
+    from smnngp.spax.models import SPR
+    n, t, d = 4096, 64, 512
+    rng = np.random.default_rng(4)
+    x = rng.standard_normal((n, d)); xt = rng.standard_normal((t, d))
+    w = rng.standard_normal(d) / np.sqrt(d)
+    y = np.tanh(x @ w) + 0.1 * rng.standard_normal(n); yt = np.tanh(xt @ w)
+    kernel = NNGPKernel(lambda ws, bs, ls: nt_kernels.get_mlp_kernel(3, 1, act="relu", w_std=ws, b_std=bs, last_w_std=ls),
+                        1.2, 0.2, 1.0)
+    model = SPR(kernel, GaussianLikelihood(), x.astype(np.float32), y.astype(np.float32), 0.0, 1.0, eps=1e-2)
+    okw = dict(kernel="mlp", num_hiddens=3, act="relu", w_std=1.2, b_std=0.2, last_w_std=1.0, eps=1e-2, method="gp")
+    rl = O.spr_loss(x, y, **okw)
+    rn, rmean, rcov = O.spr_test_nll(x, y, xt, yt, 0.0, 1.0, return_parts=True, **okw)
+    assert abs(model.loss() - rl) < 1e-2 * max(1.0, abs(rl))
+    assert abs(model.test_nll(xt.astype(np.float32), yt.astype(np.float32)) - rn) < 1e-2 * max(1.0, abs(rn))
+    mean, cov = kernel.predict(kernel.get_kernel_fn(), model.x_data, model.y_data, xt.astype(np.float32), eps=1e-2)
+    assert relerr(np.asarray(mean).ravel(), rmean.ravel()) < 1e-2
+    assert relerr(np.diagonal(np.asarray(cov)), np.diagonal(rcov)) < 1e-2
+
+
+# ----------------------------------------------------------------------------- C5: N=32768 d=1024 L=6 erf NNGP+NTK fp32
+def test_c5_erf_nngp_and_ntk_sampled_parity_and_single_gpu_lml(L, ctx):
+    n, d, nl = 32768, 1024, 6
+    rng = np.random.default_rng(5)
+    xh = rng.standard_normal((n, d)).astype(np.float32)
+    yh = rng.standard_normal(n).astype(np.float32)
+    x = ctx.to_device(xh); y = ctx.to_device(yh)
+    k = ctx.empty((n, n), np.float32); th = ctx.empty((n, n), np.float32)
+    ctx.call("smn_kernel_mlp", L.F32, L.NET_MLP, L.ACT["erf"], nl, 1.5, 0.3, 1.0, x.ptr, n, d, None, 0, 0, d,
+             L.GET_NNGP | L.GET_NTK, L.FILL_FULL, k.ptr, th.ptr, n)
+    rows = np.sort(rng.choice(n, 32, replace=False)); cols = np.sort(rng.choice(n, 48, replace=False))
+    gk = fetch_rows(L, ctx, k, rows, n, n, np.float32); gt = fetch_rows(L, ctx, th, rows, n, n, np.float32)
+    x64 = xh.astype(np.float64)
+    rk, rt = O.mlp_kernel(x64[rows], x64[cols], nl, "erf", 1.5, 0.3, 1.0, ("nngp", "ntk"))
+    assert relerr(gk[:, cols], rk) < 2e-3 and relerr(gt[:, cols], rt) < 1e-2
+    gk_t = fetch_rows(L, ctx, k, cols, n, n, np.float32)
+    assert (gk[:, cols] == gk_t[:, rows].T).all()
+    # single-GPU factorisation of the assembled kernel (the C5 flow): finite, info = 0, identities hold
+    lp, quad, logdet, info = C.c_double(), C.c_double(), C.c_double(), C.c_int()
+    ctx.call("smn_lml", L.F32, k.ptr, n, n, y.ptr, 1e-2, 0.0, 1.0, C.byref(lp), C.byref(quad), C.byref(logdet), C.byref(info))
+    assert info.value == 0 and quad.value > 0
+    assert abs(lp.value - (-0.5 * quad.value - 0.5 * n * np.log(2 * np.pi) - 0.5 * logdet.value)) < 1e-9 * abs(lp.value)
+    # the sharded build (8 ranks on one GPU) assembles the same lower triangle on the sampled rows
+    from smnngp import sharding as S
+    world = 8
+    chunk, h = S.paired_chunk_elems(n, world), S.block_rows(n, world)
+    del th
+    stage = ctx.empty((world * chunk,), np.float32); k2 = ctx.empty((n, n), np.float32)
+    for r in range(world):
+        ctx.call("smn_kernel_mlp_shard", L.F32, L.NET_MLP, L.ACT["erf"], nl, 1.5, 0.3, 1.0, x.ptr, n, d, d, world, r, h,
+                 L.GET_NNGP, C.c_void_p(stage.ptr.value + r * chunk * 4), None)
+    ctx.call("smn_unpack_lower_blocks", L.F32, stage.ptr, n, world, h, k2.ptr, n)
+    g2 = fetch_rows(L, ctx, k2, rows, n, n, np.float32)
+    for i, r in enumerate(rows):
+        assert relerr(g2[i, : r + 1], gk[i, : r + 1]) < 1e-6
+
+
+# ----------------------------------------------------------------------------- C3: CIFAR-10 shape, conv-NNGP + Student-t, fp64
+def test_c3_conv_nngp_sampled_parity_and_student_t_lml_fp64(L, ctx):
+    from smnngp import nt_kernels
+    n, layers = 10000, 4
+    rng = np.random.default_rng(6)
+    xh = rng.standard_normal((n, 32, 32, 3))
+    xh /= np.sqrt((xh ** 2).mean(axis=(1, 2, 3), keepdims=True))          # unit pixel variance, like standardised images
+    labels = rng.integers(0, 10, n)
+    yh = (labels == 3).astype(np.float64) - 0.1                             # one one-vs-rest regression target
+    kfn = nt_kernels.get_cnn_kernel(layers, act="relu", w_std=1.3, b_std=0.2, last_w_std=1.0)
+    k = kfn(xh, None, get="nngp")
+    assert k.shape == (n, n) and k.dtype == np.float64
+    rows = np.sort(rng.choice(n, 6, replace=False)); cols = np.sort(rng.choice(n, 8, replace=False))
+    got = fetch_rows(L, k.ctx, k, rows, n, n, np.float64)
+    ref = O.cnn_kernel(xh[rows], xh[cols], layers, "relu", 1.3, 0.2, 1.0)
+    assert relerr(got[:, cols], ref) < 1e-8
+    ref_d = O.cnn_kernel(xh[rows], None, layers, "relu", 1.3, 0.2, 1.0)
+    assert relerr(got[np.arange(len(rows)), rows], np.diagonal(ref_d)) < 1e-8
+    got_t = fetch_rows(L, k.ctx, k, cols, n, n, np.float64)
+    assert np.allclose(got[:, cols], got_t[:, rows].T, rtol=1e-13, atol=0)
+    # Student-t (inverse-gamma scale mixture) log-marginal likelihood on the assembled kernel, alpha = beta = 2
+    y = k.ctx.to_device(yh)
+    lp, quad, logdet, info = C.c_double(), C.c_double(), C.c_double(), C.c_int()
+    k.ctx.call("smn_lml", L.F64, k.ptr, n, n, y.ptr, 1e-4, 4.0, 1.0, C.byref(lp), C.byref(quad), C.byref(logdet), C.byref(info))
+    assert info.value == 0 and np.isfinite(lp.value) and quad.value > 0
+    import math
+    t = 0.5 * (4.0 + n)
+    want = (-t * math.log1p(quad.value / 4.0) - 0.5 * n * math.log(4.0 * math.pi) + math.lgamma(t) - math.lgamma(2.0)
+            - 0.5 * logdet.value)
+    assert abs(lp.value - want) < 1e-10 * abs(want)
