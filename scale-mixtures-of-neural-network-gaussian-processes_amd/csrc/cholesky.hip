@@ -561,11 +561,13 @@ int launch_update(smn_ctx* ctx, hipStream_t st, T* a, int64_t lda, int64_t r0, i
   }
   const size_t lds = MainTile<T>::LDS_BYTES;
   if constexpr (sizeof(T) == 4) {
-    if (tag == 1 && lower && !u.use_map && ctx->persistent_trail && nt > 2 * ctx->num_cu && K <= 512) {
+    // CUs this stream may use: the bulk stream of the look-ahead is masked off the chain's CUs
+    const int cus = (st == ctx->stream_bulk && st != nullptr) ? ctx->num_cu - ctx->chain_cus : ctx->num_cu;
+    if (tag == 1 && lower && !u.use_map && ctx->persistent_trail && nt > 2 * cus && K <= ctx->persist_max_k) {
       // persistent walk over the lower tiles, two workgroups per CU
       const size_t plds = TileNT<T, kTile, kTile, 2>::LDS_BYTES;
       ProfScope ps(ctx, PROF_TRAIL, st);
-      hipLaunchKernelGGL(trail_kernel<T>, dim3((unsigned)(2 * ctx->num_cu)), dim3(256), plds, st, u, (int)nt);
+      hipLaunchKernelGGL(trail_kernel<T>, dim3((unsigned)(2 * cus)), dim3(256), plds, st, u, (int)nt);
       SMN_CHECK_LAUNCH(ctx);
       return SMN_OK;
     }

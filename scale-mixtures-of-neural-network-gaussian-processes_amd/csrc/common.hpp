@@ -40,6 +40,7 @@ struct smn_ctx {
   bool lookahead = false;            // Cholesky look-ahead on stream2 (env SMN_LOOKAHEAD=1)
   int num_cu = 256;                  // hipDeviceProp_t::multiProcessorCount
   int64_t super_panel = 1024;        // columns per super-panel of the two-level Cholesky (env SMN_SUPER; 0 = one level)
+  int persist_max_k = 512;           // largest K the persistent trailing kernel takes (env SMN_PERSIST_MAXK)
   bool rec_sym = true;               // stand-alone recursion: lower-tile + mirror kernel when symmetric (env SMN_REC_SYM=0)
   bool persistent_trail = true;      // persistent trailing-update kernel (env SMN_PERSISTENT=0 disables)
   bool xcd_map = false;              // XCD-aware patch tile order (env SMN_XCD_MAP=1): measured 2-6 % SLOWER
