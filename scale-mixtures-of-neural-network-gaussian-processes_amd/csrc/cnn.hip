@@ -22,6 +22,16 @@ template <>
 __device__ __forceinline__ float rsqrt_any<float>(float x) { return __builtin_amdgcn_rsqf(x); }
 template <>
 __device__ __forceinline__ double rsqrt_any<double>(double x) { return 1.0 / sqrt(x); }
+template <typename T>
+__device__ __forceinline__ T rcp_any(T x);
+template <>
+__device__ __forceinline__ float rcp_any<float>(float x) { return __builtin_amdgcn_rcpf(x); }
+template <>
+__device__ __forceinline__ double rcp_any<double>(double x) {   // v_rcp_f64 + two Newton steps: full double precision
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return fma(fma(-x, r, 1.0), r, r);
+}
 
 struct ConvProg {
   int act, layers, H, W, C;
@@ -30,9 +40,13 @@ struct ConvProg {
 
 // One workgroup per image: Q[img][l][p] = pre-activation variance of layer l at pixel p,
 // diag[img] = last_w^2 * mean_p q_L (the exact K(img, img)).
+// R is what the pair kernel multiplies (like the r table of the MLP build); ONE table, because the pair kernel is
+// bound by streaming these tables out of L2, not by its arithmetic:
+//   ReLU: r = 1/sqrt(q~) (0 where q~ <= 0); the second factor s_i s_j = sqrt(q_i q_j)/(2 pi) = 1/(2 pi r_i r_j)
+//   erf:  r = 1/sqrt(1 + 2 q~)
 template <typename T>
 __global__ void __launch_bounds__(256) conv_q_kernel(const T* __restrict__ x, int64_t n, ConvProg p,
-                                                     T* __restrict__ Q, T* __restrict__ diag) {
+                                                     T* __restrict__ R, T* __restrict__ diag) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int H = p.H, W = p.W, HW = H * W, PW = W + 2, PSZ = (H + 2) * PW;
   double* m0 = reinterpret_cast<double*>(smem);   // padded map, double for the diagonal
@@ -55,7 +69,9 @@ __global__ void __launch_bounds__(256) conv_q_kernel(const T* __restrict__ x, in
       const double* c = cur + h * PW + w;   // top-left of the 3x3 window in the padded map
       const double bs = c[0] + c[1] + c[2] + c[PW] + c[PW + 1] + c[PW + 2] + c[2 * PW] + c[2 * PW + 1] + c[2 * PW + 2];
       const double qt = p.w2 * bs / 9.0 + p.b2;
-      Q[(img * p.layers + l) * HW + px] = (T)qt;
+      const int64_t ti = (img * p.layers + l) * HW + px;
+      if (p.act == 0) R[ti] = qt > 0.0 ? (T)(1.0 / sqrt(qt)) : T(0);
+      else R[ti] = (T)(1.0 / sqrt(1.0 + 2.0 * qt));
       const double qa = p.act == 0 ? 0.5 * qt : (2.0 / nngp::kPi) * asin(2.0 * qt / (1.0 + 2.0 * qt));
       nxt[(h + 1) * PW + w + 1] = qa;
     }
@@ -77,16 +93,18 @@ __global__ void __launch_bounds__(256) conv_q_kernel(const T* __restrict__ x, in
 
 template <typename T>
 struct PairArgs {
-  const T* x1; const T* x2; const T* Q1; const T* Q2; const T* diag;
+  const T* x1; const T* x2; const T* R1; const T* R2; const T* diag;
   int64_t n1, n2; int symmetric, mirror;
   ConvProg prog;
   T* out; int64_t ldo; int64_t npairs;
 };
 
-constexpr int kMaxPix = 64;   // pixels per lane held in registers between phases (H*W <= 4096)
+constexpr int kMaxPix = 64;   // pixels per lane (H*W <= 4096)
 
-// 4 waves per workgroup, one image pair per wave per iteration.
-template <typename T, int ACT>
+// 4 waves per workgroup, each wave walks its own list of image pairs: the two maps of a wave are private to it,
+// LDS operations of one wave execute in order, so the layers need no workgroup barrier (only a compiler fence).
+// NP = pixels per lane (compile-time bound): padded-map offsets are computed once per kernel, not per layer.
+template <typename T, int ACT, int NP, bool EXACT>   // EXACT: H*W == 64*NP, no per-pixel guards
 __global__ void __launch_bounds__(256) conv_pair_kernel(PairArgs<T> a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const ConvProg& p = a.prog;
@@ -95,73 +113,98 @@ __global__ void __launch_bounds__(256) conv_pair_kernel(PairArgs<T> a) {
   T* buf0 = reinterpret_cast<T*>(smem) + (size_t)wave * 2 * PSZ;
   T* buf1 = buf0 + PSZ;
   for (int i = lane; i < 2 * PSZ; i += 64) buf0[i] = T(0);   // halo stays zero for the whole kernel
+  int off[NP];                                               // centre of pixel lane + 64 i in the padded map
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const int px = lane + 64 * i;
+    off[i] = (EXACT || px < HW) ? (px / W + 1) * PW + px % W + 1 : -1;
+  }
   const T w2_9 = (T)(p.w2 / 9.0), b2 = (T)p.b2;
   const T inv_c = (T)(1.0 / p.C);
   const int64_t stride = (int64_t)gridDim.x * 4;
-  // every wave of the workgroup runs the same number of iterations (barriers inside the loop)
-  const int64_t iters = (a.npairs + stride - 1) / stride;
-  for (int64_t it = 0; it < iters; ++it) {
-    const int64_t pr = (int64_t)blockIdx.x * 4 + wave + it * stride;
-    const bool live = pr < a.npairs;
-    int64_t n = 0, m = 0;
-    if (live) {
-      if (a.symmetric) {
-        int64_t r = (int64_t)((sqrt(8.0 * (double)pr + 1.0) - 1.0) * 0.5);
-        while ((r + 1) * (r + 2) / 2 <= pr) ++r;
-        while (r * (r + 1) / 2 > pr) --r;
-        n = r;
-        m = pr - r * (r + 1) / 2;
-      } else {
-        n = pr / a.n2;
-        m = pr % a.n2;
-      }
+  for (int64_t pr = (int64_t)blockIdx.x * 4 + wave; pr < a.npairs; pr += stride) {
+    int64_t n, m;
+    if (a.symmetric) {
+      int64_t r = (int64_t)((sqrt(8.0 * (double)pr + 1.0) - 1.0) * 0.5);
+      while ((r + 1) * (r + 2) / 2 <= pr) ++r;
+      while (r * (r + 1) / 2 > pr) --r;
+      n = r;
+      m = pr - r * (r + 1) / 2;
+    } else {
+      n = pr / a.n2;
+      m = pr % a.n2;
     }
+    __builtin_amdgcn_wave_barrier();   // the previous pair's reads of the maps are done (same wave, in order)
     // K0 map
     const T* xa = a.x1 + n * HW * p.C;
     const T* xb = a.x2 + m * HW * p.C;
-    for (int px = lane; px < HW; px += 64) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      if (!EXACT && off[i] < 0) continue;
+      const int px = lane + 64 * i;
       T s = T(0);
       for (int c = 0; c < p.C; ++c) s = fma(xa[px * p.C + c], xb[px * p.C + c], s);
-      buf0[(px / W + 1) * PW + px % W + 1] = live ? s * inv_c : T(0);
+      buf0[off[i]] = s * inv_c;
     }
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     T* cur = buf0;
     T* nxt = buf1;
     for (int l = 0; l < p.layers; ++l) {
-      const T* q1 = a.Q1 + (n * p.layers + l) * HW;
-      const T* q2 = a.Q2 + (m * p.layers + l) * HW;
-      for (int px = lane; px < HW; px += 64) {
-        const int h = px / W, w = px % W;
-        const T* c = cur + h * PW + w;
-        const T bs = c[0] + c[1] + c[2] + c[PW] + c[PW + 1] + c[PW + 2] + c[2 * PW] + c[2 * PW + 1] + c[2 * PW + 2];
+      const int64_t t1 = (n * p.layers + l) * HW + lane, t2 = (m * p.layers + l) * HW + lane;
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        if (!EXACT && off[i] < 0) continue;
+        const T rr = a.R1[t1 + 64 * i] * a.R2[t2 + 64 * i];
+        const T* c = cur + off[i];
+        const T bs = ((c[-PW - 1] + c[-PW]) + (c[-PW + 1] + c[-1])) + ((c[0] + c[1]) + (c[PW - 1] + c[PW])) + c[PW + 1];
         const T kt = fma(w2_9, bs, b2);
         T kn;
         if (ACT == 0) {
-          const T pp = q1[px] * q2[px];
-          const T rp = pp > T(0) ? rsqrt_any<T>(pp) : T(0);
-          kn = nngp::relu_map<T, false>(kt, rp, pp * rp * T(1.0 / (2.0 * nngp::kPi))).k;
+          const T ss = rr > T(0) ? T(1.0 / (2.0 * nngp::kPi)) * rcp_any<T>(rr) : T(0);
+          kn = nngp::relu_map<T, false>(kt, rr, ss).k;
         } else {
-          const T pp = (T(1) + T(2) * q1[px]) * (T(1) + T(2) * q2[px]);
-          kn = nngp::erf_map<T, false>(kt, rsqrt_any<T>(pp), T(0)).k;
+          kn = nngp::erf_map<T, false>(kt, rr, T(0)).k;
         }
-        nxt[(h + 1) * PW + w + 1] = kn;
+        nxt[off[i]] = kn;
       }
-      __syncthreads();
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
       T* t = cur; cur = nxt; nxt = t;
     }
     // Flatten (mean over pixels) + last Dense
     T s = T(0);
-    for (int px = lane; px < HW; px += 64) s += cur[(px / W + 1) * PW + px % W + 1];
+#pragma unroll
+    for (int i = 0; i < NP; ++i)
+      if (EXACT || off[i] >= 0) s += cur[off[i]];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    if (live && lane == 0) {
+    if (lane == 0) {
       T v = (T)p.lw2 * s / (T)HW;
       if (a.symmetric && n == m) v = a.diag[n];
       a.out[n * a.ldo + m] = v;
       if (a.symmetric && a.mirror && n != m) a.out[m * a.ldo + n] = v;
     }
-    __syncthreads();   // the maps are rewritten by the next pair
   }
+}
+
+template <typename T, int ACT>
+int launch_pairs(smn_ctx* ctx, const PairArgs<T>& a, int64_t blocks, size_t lds, int64_t hw) {
+#define PAIR_CASE(NP)                                                                                              \
+  if (hw <= 64 * NP) {                                                                                             \
+    /* the guard-free form pays in f64 (+9 %); in f32 it costs a wave of occupancy and 12 % (cnn_probe) */         \
+    auto kern = (hw == 64 * NP && sizeof(T) == 8) ? conv_pair_kernel<T, ACT, NP, true>                             \
+                                                  : conv_pair_kernel<T, ACT, NP, false>;                           \
+    SMN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    ProfScope ps(ctx, PROF_BUILD, ctx->stream);                                                                    \
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, ctx->stream, a);                              \
+    return SMN_OK;                                                                                                 \
+  }
+  PAIR_CASE(4)
+  PAIR_CASE(16)
+  PAIR_CASE(kMaxPix)
+#undef PAIR_CASE
+  return smn_fail(ctx, SMN_ENOTSUP, "smn_kernel_cnn: H*W > %d", 64 * kMaxPix);
 }
 
 template <typename T>
@@ -176,42 +219,33 @@ int cnn_t(smn_ctx* ctx, int act, int layers, double w, double b, double lw, cons
   const size_t lds_p = 4 * 2 * psz * sizeof(T);
   if (lds_q > 160 * 1024 || lds_p > 160 * 1024)
     return smn_fail(ctx, SMN_ENOTSUP, "smn_kernel_cnn: image %lldx%lld too large for the on-chip pair map", (long long)H, (long long)W);
-  // tables: Q1 [n1][L][HW], diag1 [n1] (+ Q2, diag2)
+  // tables: R1 [n1][L][HW], diag1 [n1] (+ R2, diag2)
   const size_t qn1 = (size_t)n1 * (size_t)(layers > 0 ? layers : 1) * HW, qn2 = sym ? 0 : (size_t)n2 * (size_t)(layers > 0 ? layers : 1) * HW;
   void* tv = nullptr;
   SMN_TRY(smn_workspace(ctx, 1, sizeof(T) * (qn1 + qn2 + (size_t)n1 + (size_t)n2), &tv));
-  T* Q1 = static_cast<T*>(tv);
-  T* Q2 = sym ? Q1 : Q1 + qn1;
-  T* d1 = Q1 + qn1 + qn2;
+  T* R1 = static_cast<T*>(tv);
+  T* R2 = sym ? R1 : R1 + qn1;
+  T* d1 = R1 + qn1 + qn2;
   T* d2 = d1 + n1;
   {
     ProfScope ps(ctx, PROF_PREP, ctx->stream);
     SMN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_q_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q));
     hipLaunchKernelGGL(conv_q_kernel<T>, dim3((unsigned)n1), dim3(256), lds_q, ctx->stream,
-                       static_cast<const T*>(x1), n1, p, Q1, d1);
+                       static_cast<const T*>(x1), n1, p, R1, d1);
     if (!sym)
       hipLaunchKernelGGL(conv_q_kernel<T>, dim3((unsigned)n2), dim3(256), lds_q, ctx->stream,
-                         static_cast<const T*>(x2), n2, p, Q2, d2);
+                         static_cast<const T*>(x2), n2, p, R2, d2);
   }
   SMN_CHECK_LAUNCH(ctx);
   PairArgs<T> a;
   a.x1 = static_cast<const T*>(x1); a.x2 = sym ? a.x1 : static_cast<const T*>(x2);
-  a.Q1 = Q1; a.Q2 = Q2; a.diag = d1; a.n1 = n1; a.n2 = n2;
+  a.R1 = R1; a.R2 = R2; a.diag = d1; a.n1 = n1; a.n2 = n2;
   a.symmetric = sym ? 1 : 0; a.mirror = (sym && fill == SMN_FILL_FULL) ? 1 : 0;
   a.prog = p; a.out = static_cast<T*>(out); a.ldo = ldk;
   a.npairs = sym ? n1 * (n1 + 1) / 2 : n1 * n2;
   int64_t blocks = (a.npairs + 3) / 4;
   if (blocks > 256 * 8) blocks = 256 * 8;   // persistent-ish: waves stride over the pair list
-  {
-    ProfScope ps(ctx, PROF_BUILD, ctx->stream);
-    if (act == SMN_ACT_RELU) {
-      SMN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pair_kernel<T, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p));
-      hipLaunchKernelGGL((conv_pair_kernel<T, 0>), dim3((unsigned)blocks), dim3(256), lds_p, ctx->stream, a);
-    } else {
-      SMN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pair_kernel<T, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p));
-      hipLaunchKernelGGL((conv_pair_kernel<T, 1>), dim3((unsigned)blocks), dim3(256), lds_p, ctx->stream, a);
-    }
-  }
+  SMN_TRY(act == SMN_ACT_RELU ? (launch_pairs<T, 0>(ctx, a, blocks, lds_p, HW)) : (launch_pairs<T, 1>(ctx, a, blocks, lds_p, HW)));
   SMN_CHECK_LAUNCH(ctx);
   return SMN_OK;
 }
