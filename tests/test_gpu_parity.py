@@ -393,6 +393,50 @@ def test_cholesky_more_workgroups_than_cus_and_lookahead(L, ctx, dtype, n, m):
         assert relerr(np.tril(got[n:, n:]), np.tril(a[n:, n:] - w @ w.T)) < tol
 
 
+@pytest.mark.parametrize("env", [
+    {"SMN_CHAIN_CUS": "0"},                                    # two-level, serial
+    {"SMN_CHAIN_CUS": "64"},                                   # masked look-ahead, other reservation
+    {"SMN_SUPER": "0", "SMN_CHAIN_CUS": "0"},                  # one level
+    {"SMN_LOOKAHEAD": "1"},                                    # one-level look-ahead, updates on the masked stream
+    {"SMN_LOOKAHEAD": "1", "SMN_CHAIN_CUS": "0"},              # one-level look-ahead on plain streams
+    {"SMN_PERSISTENT": "0"},
+    {"SMN_PERSIST_MAXK": "1024"},
+    {"SMN_SUPER": "2048"},
+    {"SMN_XCD_MAP": "1"},
+])
+def test_cholesky_schedule_variants_agree(L, env):
+    """Every schedule the environment switches select factors the same matrix to the same result (the default
+    one is checked against LAPACK above): n = 8192 + 128 appended rows, fp32."""
+    import os
+    n, m = 8192, 128
+    rng = np.random.default_rng(5)
+    g = rng.standard_normal((n + m, 96)).astype(np.float32)
+    a = (g @ g.T / 96 + np.diag(rng.uniform(1.0, 2.0, n + m))).astype(np.float32)
+
+    def run(extra):
+        old = {k: os.environ.get(k) for k in extra}
+        os.environ.update(extra)
+        try:
+            c = L.Context(0)
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    del os.environ[k]
+                else:
+                    os.environ[k] = v
+        ad = c.to_device(a)
+        info, logdet = C.c_int(), C.c_double()
+        c.call("smn_cholesky", L.F32, ad.ptr, n + m, n, n + m, 0, 0.0, 0.0, C.byref(info), C.byref(logdet))
+        return info.value, logdet.value, ad.numpy()
+
+    i0, ld0, f0 = run({})
+    i1, ld1, f1 = run(env)
+    # different K groupings round differently in fp32: agreement to fp32 accumulation accuracy, not bit for bit
+    assert i0 == 0 and i1 == 0 and abs(ld1 - ld0) < 1e-5 * abs(ld0)
+    il = np.tril_indices(n + m)
+    assert relerr(f1[il], f0[il]) < 1e-4
+
+
 def test_cholesky_shift_and_not_pd(L, ctx):
     rng = np.random.default_rng(11)
     n = 200
