@@ -111,7 +111,8 @@ template <typename T>
 __global__ void __launch_bounds__(PanelCfg<T>::THREADS) panel_kernel(T* __restrict__ a, int64_t lda, int64_t j0,
                                                                      int64_t rbeg, int64_t n_total, int prefactored,
                                                                      double* __restrict__ logdet,
-                                                                     int* __restrict__ info, T* __restrict__ ldiag_out) {
+                                                                     int* __restrict__ info, T* __restrict__ ldiag_out,
+                                                                     int64_t id0, int64_t id1) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int XR = PanelCfg<T>::XR, NT = PanelCfg<T>::THREADS, LD = PanelCfg<T>::LD;
   constexpr int VEC = 16 / sizeof(T);
@@ -121,6 +122,8 @@ __global__ void __launch_bounds__(PanelCfg<T>::THREADS) panel_kernel(T* __restri
   T* piv = blk + MP * MP;                   // [PB] pivots d_j = L_jj^2 (for logdet / info)
   const int tid = threadIdx.x;
   const int64_t rb = rbeg + (int64_t)blockIdx.x * XR;  // first appended row of this workgroup
+  // identity rows that start right of this sub-panel are zero in its columns and stay zero
+  if (id0 >= 0 && rb >= id0 && rb + XR <= id1 && rb - id0 >= j0 + PB) return;
   const int nx = (int)max((int64_t)0, min((int64_t)XR, n_total - rb));
   // global -> LDS in 16-byte pieces (rows are 16-byte aligned on both sides).  SI loads per thread are in flight
   // at once, and the first round of the appended rows is issued before the diagonal block's LDS writes.
@@ -346,6 +349,9 @@ template <typename T>
 struct UpdArgs {
   T* a; int64_t lda; int64_t r0, c0, k0; int K; int tiles_n; int lower;
   int use_map; TileMap map;   // XCD-aware patch order (gemm_nt.hpp) instead of the linear one
+  // identity rows [id0, id1) (id0 < 0: none): a tile whose rows lie inside them and start right of the K range
+  // multiplies zeros -- the workgroup leaves at once
+  int64_t id0, id1;
 };
 
 template <typename T>
@@ -380,6 +386,7 @@ __global__ void __launch_bounds__(256, sizeof(T) == 8 ? 1 : 2) update_kernel(Upd
     upd_decode(u, (int)blockIdx.x, tr, tc);
   }
   const int64_t row0 = u.r0 + (int64_t)tr * kTile, col0 = u.c0 + (int64_t)tc * kTile;
+  if (u.id0 >= 0 && row0 >= u.id0 && row0 + kTile <= u.id1 && row0 - u.id0 >= u.k0 + u.K) return;
   Tile t;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wr = wave >> 1, wc = wave & 1;
@@ -551,7 +558,8 @@ int launch_update(smn_ctx* ctx, hipStream_t st, T* a, int64_t lda, int64_t r0, i
     lower = 1;
     tiles_n = tiles_m;
   }
-  UpdArgs<T> u{a, lda, r0, c0, k0, K, (int)tiles_n, lower, 0, TileMap::make(tiles_m, tiles_n, lower == 1)};
+  UpdArgs<T> u{a, lda, r0, c0, k0, K, (int)tiles_n, lower, 0, TileMap::make(tiles_m, tiles_n, lower == 1),
+               ctx->chol_id0, ctx->chol_id1};
   int64_t nt = lower == 1   ? tiles_m * (tiles_m + 1) / 2
                : lower == 2 ? tiles_n * (tiles_n + 1) / 2 + (tiles_m - tiles_n) * tiles_n
                             : tiles_m * tiles_n;
@@ -563,7 +571,8 @@ int launch_update(smn_ctx* ctx, hipStream_t st, T* a, int64_t lda, int64_t r0, i
   if constexpr (sizeof(T) == 4) {
     // CUs this stream may use: the bulk stream of the look-ahead is masked off the chain's CUs
     const int cus = (st == ctx->stream_bulk && st != nullptr) ? ctx->num_cu - ctx->chain_cus : ctx->num_cu;
-    if (tag == 1 && lower && !u.use_map && ctx->persistent_trail && nt > 2 * cus && K <= ctx->persist_max_k) {
+    if (tag == 1 && lower && !u.use_map && ctx->persistent_trail && nt > 2 * cus && K <= ctx->persist_max_k &&
+        ctx->chol_id0 < 0) {   // the persistent walk has no tile skipping
       // persistent walk over the lower tiles, two workgroups per CU
       const size_t plds = TileNT<T, kTile, kTile, 2>::LDS_BYTES;
       ProfScope ps(ctx, PROF_TRAIL, st);
@@ -598,7 +607,7 @@ int launch_panel(smn_ctx* ctx, hipStream_t st, T* a, int64_t lda, int64_t j0, in
     ProfScope ps(ctx, PROF_PANEL, st);
     T* ldiag = reinterpret_cast<T*>(ctx->ws[3]) + (j0 / PB) * (int64_t)(PB * PB);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(PanelCfg<T>::THREADS), lds, st, a, lda, j0, rbeg, n_total, prefactored,
-                       ctx->d_scal, ctx->d_info, ldiag);
+                       ctx->d_scal, ctx->d_info, ldiag, ctx->chol_id0, ctx->chol_id1);
   }
   SMN_CHECK_LAUNCH(ctx);
   return SMN_OK;
@@ -755,16 +764,23 @@ int cholesky_t(smn_ctx* ctx, T* a, int64_t n_total, int64_t n_factor, int64_t ld
 }  // namespace
 
 int cholesky_padded(smn_ctx* ctx, int dtype, void* a, int64_t n_total, int64_t n_factor, int64_t lda, int64_t n_shift,
-                    double jitter_abs, double ridge_rel, bool keep_factor) {
+                    double jitter_abs, double ridge_rel, bool keep_factor, int64_t id0, int64_t id1) {
   if (n_total % kTile || n_factor % kTile || n_factor > n_total || n_factor <= 0)
     return smn_fail(ctx, SMN_EINVAL, "cholesky_padded: n_total=%lld n_factor=%lld must be multiples of %d",
                     (long long)n_total, (long long)n_factor, kTile);
   if (lda % (16 / (int)dtype_size(dtype)) || (reinterpret_cast<uintptr_t>(a) & 15))
     return smn_fail(ctx, SMN_EINVAL, "cholesky_padded: matrix must be 16-byte aligned");
-  if (dtype == SMN_F64)
-    return cholesky_t<double>(ctx, static_cast<double*>(a), n_total, n_factor, lda, n_shift, jitter_abs, ridge_rel,
-                              keep_factor);
-  return cholesky_t<float>(ctx, static_cast<float*>(a), n_total, n_factor, lda, n_shift, jitter_abs, ridge_rel, keep_factor);
+  if (id0 >= 0 && (id0 < n_factor || id0 % kTile || id1 < id0 || id1 > n_total))
+    return smn_fail(ctx, SMN_EINVAL, "cholesky_padded: bad identity-row hint");
+  ctx->chol_id0 = id0;
+  ctx->chol_id1 = id0 >= 0 ? id1 : -1;
+  const int rc = dtype == SMN_F64
+                     ? cholesky_t<double>(ctx, static_cast<double*>(a), n_total, n_factor, lda, n_shift, jitter_abs,
+                                          ridge_rel, keep_factor)
+                     : cholesky_t<float>(ctx, static_cast<float*>(a), n_total, n_factor, lda, n_shift, jitter_abs, ridge_rel,
+                                         keep_factor);
+  ctx->chol_id0 = ctx->chol_id1 = -1;
+  return rc;
 }
 
 // Solve-only sweep: rows [n_factor, n_total) of `a` <- rows * L^-T with L = the (already factored)
@@ -789,13 +805,13 @@ int solve_rows_padded(smn_ctx* ctx, int dtype, void* a, int64_t n_total, int64_t
       const unsigned grid = (unsigned)((n_total - n_factor + XR - 1) / XR);
       hipLaunchKernelGGL(panel_kernel<double>, dim3(grid), dim3(PanelCfg<double>::THREADS),
                          panel_lds_bytes<double>(), st, static_cast<double*>(a), lda, js, n_factor,
-                         n_total, 1, ctx->d_scal, ctx->d_info, static_cast<double*>(nullptr));
+                         n_total, 1, ctx->d_scal, ctx->d_info, static_cast<double*>(nullptr), (int64_t)-1, (int64_t)-1);
     } else {
       constexpr int XR = PanelCfg<float>::XR;
       const unsigned grid = (unsigned)((n_total - n_factor + XR - 1) / XR);
       hipLaunchKernelGGL(panel_kernel<float>, dim3(grid), dim3(PanelCfg<float>::THREADS),
                          panel_lds_bytes<float>(), st, static_cast<float*>(a), lda, js, n_factor,
-                         n_total, 1, ctx->d_scal, ctx->d_info, static_cast<float*>(nullptr));
+                         n_total, 1, ctx->d_scal, ctx->d_info, static_cast<float*>(nullptr), (int64_t)-1, (int64_t)-1);
     }
     SMN_CHECK_LAUNCH(ctx);
   }

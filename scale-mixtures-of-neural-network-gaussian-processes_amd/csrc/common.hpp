@@ -40,6 +40,9 @@ struct smn_ctx {
   bool lookahead = false;            // Cholesky look-ahead on stream2 (env SMN_LOOKAHEAD=1)
   int num_cu = 256;                  // hipDeviceProp_t::multiProcessorCount
   int64_t super_panel = 1024;        // columns per super-panel of the two-level Cholesky (env SMN_SUPER; 0 = one level)
+  // structural-zero hint for the factorisation in flight: appended rows [id0, id1) hold an identity block
+  // (row id0 + i is zero left of column i), set by cholesky_padded, -1 = none
+  int64_t chol_id0 = -1, chol_id1 = -1;
   int persist_max_k = 512;           // largest K the persistent trailing kernel takes (env SMN_PERSIST_MAXK)
   bool rec_sym = true;               // stand-alone recursion: lower-tile + mirror kernel when symmetric (env SMN_REC_SYM=0)
   bool persistent_trail = true;      // persistent trailing-update kernel (env SMN_PERSISTENT=0 disables)

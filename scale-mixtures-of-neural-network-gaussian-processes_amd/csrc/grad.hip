@@ -307,7 +307,7 @@ extern "C" int smn_spr_loss_grad(smn_ctx* ctx, int dtype, int net, int act, int 
   SMN_CHECK_LAUNCH(ctx);
   double quad = 0.0, logdet = 0.0;
   int info = 0;
-  SMN_TRY(smn_predict(ctx, dtype, joint, n, n, ldj, y_d, 1, 0.0, eps_abs, alpha, ninv, ld0, &quad, &logdet, &info));
+  SMN_TRY(predict_joint(ctx, dtype, joint, n, n, ldj, y_d, 1, 0.0, eps_abs, alpha, ninv, ld0, &quad, &logdet, &info, true));
   if (quad_h) *quad_h = quad;
   if (logdet_h) *logdet_h = logdet;
   if (info_h) *info_h = info;

@@ -80,9 +80,12 @@ int aug_build(smn_ctx* ctx, const BuildSpec& spec, const Aug& g, const void* x, 
 }
 
 int aug_finish(smn_ctx* ctx, int dtype, const Aug& g, const void* y, int64_t ldy, int64_t n_shift, double jitter_abs,
-               double ridge_rel, void* mean, void* cov, int64_t ldcov, double* quad_h, double* logdet_h, int* info_h) {
+               double ridge_rel, void* mean, void* cov, int64_t ldcov, double* quad_h, double* logdet_h, int* info_h,
+               bool td_identity = false) {
   SMN_TRY(set_aug_rows(ctx, dtype, g.a, g.lda, g.n_pad + g.t, g.n_total, y, g.n, g.c, ldy));
-  SMN_TRY(cholesky_padded(ctx, dtype, g.a, g.n_total, g.n_pad, g.lda, n_shift, jitter_abs, ridge_rel, false));
+  // identity test rows: whole 128-row tiles of them may be skipped where they are structurally zero
+  const int64_t id0 = td_identity ? g.n_pad : -1, id1 = td_identity ? g.n_pad + g.t / kTile * kTile : -1;
+  SMN_TRY(cholesky_padded(ctx, dtype, g.a, g.n_total, g.n_pad, g.lda, n_shift, jitter_abs, ridge_rel, false, id0, id1));
   double* quad_dev = ctx->d_scal + 8;
   if (g.c > 48) return smn_fail(ctx, SMN_ENOTSUP, "more than 48 output columns");
   SMN_TRY(extract_posterior(ctx, dtype, g.a, g.lda, g.n_pad, g.t, g.c, mean, cov, ldcov, quad_dev));
@@ -190,9 +193,9 @@ extern "C" int smn_lml(smn_ctx* ctx, int dtype, void* k_d, int64_t n, int64_t ld
   return SMN_OK;
 }
 
-extern "C" int smn_predict(smn_ctx* ctx, int dtype, void* kj_d, int64_t n, int64_t t, int64_t ldk, const void* y_d,
-                           int64_t c, double ridge_rel, double ridge_abs, void* mean_d, void* cov_d, int64_t ldcov,
-                           double* quad_h, double* logdet_h, int* info_h) {
+int predict_joint(smn_ctx* ctx, int dtype, void* kj_d, int64_t n, int64_t t, int64_t ldk, const void* y_d, int64_t c,
+                  double ridge_rel, double ridge_abs, void* mean_d, void* cov_d, int64_t ldcov, double* quad_h,
+                  double* logdet_h, int* info_h, bool td_identity) {
   if (!ctx || !kj_d || !y_d) return SMN_EINVAL;
   if (dtype != SMN_F32 && dtype != SMN_F64) return smn_fail(ctx, SMN_EINVAL, "bad dtype");
   if (n <= 0 || t < 0 || c <= 0) return smn_fail(ctx, SMN_EINVAL, "smn_predict: bad sizes");
@@ -204,7 +207,15 @@ extern "C" int smn_predict(smn_ctx* ctx, int dtype, void* kj_d, int64_t n, int64
   SMN_TRY(copy_matrix(ctx, dtype, g.at(g.n_pad, 0), g.lda, kb + g.es * (size_t)(n * ldk), ldk, t, n, 0));
   SMN_TRY(copy_matrix(ctx, dtype, g.at(g.n_pad, g.n_pad), g.lda, kb + g.es * (size_t)(n * ldk + n), ldk, t, t, 1));
   SMN_TRY(fill_identity_pad(ctx, dtype, g.a, g.lda, g.n_pad, n));
-  return aug_finish(ctx, dtype, g, y_d, c, n, ridge_abs, ridge_rel, mean_d, cov_d, ldcov, quad_h, logdet_h, info_h);
+  return aug_finish(ctx, dtype, g, y_d, c, n, ridge_abs, ridge_rel, mean_d, cov_d, ldcov, quad_h, logdet_h, info_h,
+                    td_identity && t == n);
+}
+
+extern "C" int smn_predict(smn_ctx* ctx, int dtype, void* kj_d, int64_t n, int64_t t, int64_t ldk, const void* y_d,
+                           int64_t c, double ridge_rel, double ridge_abs, void* mean_d, void* cov_d, int64_t ldcov,
+                           double* quad_h, double* logdet_h, int* info_h) {
+  return predict_joint(ctx, dtype, kj_d, n, t, ldk, y_d, c, ridge_rel, ridge_abs, mean_d, cov_d, ldcov, quad_h, logdet_h,
+                       info_h, false);
 }
 
 extern "C" int smn_spr_loss(smn_ctx* ctx, int dtype, int net, int act, int num_hiddens, double w_std, double b_std,

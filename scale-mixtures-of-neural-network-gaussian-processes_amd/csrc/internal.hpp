@@ -44,7 +44,13 @@ inline int64_t k_pad(int dtype, int64_t d) { return round_up(d, dtype == SMN_F64
 // Partial Cholesky on a padded matrix (n_total, n_factor multiples of 128).  Device-side results:
 // logdet (double) and info (int) are left in ctx->d_scal[0] / ctx->d_info[0]; no host sync.
 int cholesky_padded(smn_ctx* ctx, int dtype, void* a, int64_t n_total, int64_t n_factor, int64_t lda,
-                    int64_t n_shift, double jitter_abs, double ridge_rel, bool keep_factor);
+                    int64_t n_shift, double jitter_abs, double ridge_rel, bool keep_factor,
+                    int64_t id0 = -1, int64_t id1 = -1);   // id0/id1: appended rows [id0, id1) are an identity block
+// smn_predict with a promise about K_td: td_identity = the test rows of kj_d are [I, 0] (t == n), which lets the
+// factorisation skip their structural zeros (analytic gradients: alpha and -K~^-1 from one factorisation)
+int predict_joint(smn_ctx* ctx, int dtype, void* kj_d, int64_t n, int64_t t, int64_t ldk, const void* y_d, int64_t c,
+                  double ridge_rel, double ridge_abs, void* mean_d, void* cov_d, int64_t ldcov, double* quad_h,
+                  double* logdet_h, int* info_h, bool td_identity);
 int fetch_logdet_info(smn_ctx* ctx, double* logdet, int* info);
 
 // small helpers implemented in util.hip

@@ -740,6 +740,36 @@ def test_analytic_loss_gradient_matches_finite_differences_of_the_oracle(dtype, 
         assert abs(got - ref[k]) < tol * max(scale, abs(ref[k])), (k, got, ref[k])
 
 
+@pytest.mark.parametrize("dtype,n", [(np.float64, 700), (np.float64, 1280), (np.float32, 1100)])
+def test_analytic_gradient_at_sizes_that_skip_identity_tiles(dtype, n):
+    """The gradient's factorisation carries an N x N identity block whose structurally zero tiles are skipped
+    (several tile rows here, with and without a ragged last tile); values must not change."""
+    from smnngp import nt_kernels
+    from smnngp.spax.kernels import NNGPKernel
+    from smnngp.spax.likelihoods import StudentTLikelihood
+    from smnngp.spax.models import SPR
+    rng = np.random.default_rng(n)
+    d = 5
+    x = rng.standard_normal((n, d)); y = np.cos(x[:, 0]) + 0.3 * rng.standard_normal(n)
+    hyp = dict(w_std=1.1, b_std=0.3, last_w_std=1.2, eps=5e-2, alpha=2.0, beta=1.5)
+    kernel = NNGPKernel(lambda w, b, l: nt_kernels.get_mlp_kernel(2, 1, act="relu", w_std=w, b_std=b, last_w_std=l),
+                        hyp["w_std"], hyp["b_std"], hyp["last_w_std"])
+    lik = StudentTLikelihood(hyp["alpha"], hyp["beta"])
+    model = SPR(kernel, lik, x.astype(dtype), y.astype(dtype), 0.0, 1.0, eps=hyp["eps"])
+    loss, grads = model.loss_and_grad()
+    okw = dict(kernel="mlp", num_hiddens=2, act="relu", method="tp", **hyp)
+    ref = O.spr_loss_grad_fd(x, y, **okw)
+    assert abs(loss - O.spr_loss(x, y, **okw)) < (1e-9 if dtype == np.float64 else 1e-3)
+    vmap = {"w_std": kernel.w_std, "b_std": kernel.b_std, "last_w_std": kernel.last_w_std, "eps": model.eps,
+            "alpha": lik.a, "beta": lik.b}
+    names = {id(v): k for k, v in model.vars().items()}
+    scale = max(abs(v) for v in ref.values())
+    tol = 5e-6 if dtype == np.float64 else 2e-2
+    for k, var in vmap.items():
+        got = grads[names[id(var)]] / float(var.constraint.grad(var.value))
+        assert abs(got - ref[k]) < tol * max(scale, abs(ref[k])), (k, got, ref[k])
+
+
 def test_analytic_train_step_descends_and_agrees_with_fd_step():
     """regression/train.py:61-67 with the analytic gradient: same first Adam update as finite differences."""
     from smnngp import nt_kernels, train
