@@ -10,14 +10,24 @@
 // -y^T K^-1 y drop out of the same trailing update that the factorisation needs anyway, so the
 // path has no separate triangular-solve kernels.
 //
-// Right-looking, two levels:  outer panels of 256 columns, inner 128-column sub-panels.
-//   panel_kernel   one workgroup per block of rows below the diagonal block; every workgroup
-//                  re-factors the 128x128 diagonal block in LDS (unblocked, right-looking) and
-//                  carries its own rows through the same column operations (a true TRSM, no
-//                  explicit inverse).  Workgroup 0 stores L_kk, sum(log pivots) and the info flag.
-//   update_kernel  C -= A B^T on the f32/f64 MFMA (gemm_nt.hpp): the 128-wide strip update in
-//                  front of the second sub-panel (K=128) and the trailing update (K=256, lower
-//                  tiles only), where nearly all the N^3/3 flops are.
+// Right-looking.  Columns are cut three ways: super-panels of S = 1024 columns, outer panels of 256 inside them,
+// 128-column sub-panels inside those.
+//   panel_kernel   one workgroup per block of rows below the diagonal block; every workgroup re-factors the
+//                  128x128 diagonal block in LDS and carries its own rows through the same column operations
+//                  (a true TRSM, no explicit inverse): 16-column blocks are brought up to date with MFMAs
+//                  straight from the LDS image, 8-column micro-panels are factored in registers.
+//                  Workgroup 0 stores L_kk (to a side buffer), sum(log pivots) and the info flag.
+//   update_kernel  C -= A B^T on the f32/f64 MFMA (gemm_nt.hpp), four uses:
+//     strip   the 128 columns in front of the second sub-panel (K = 128);
+//     near    after an outer panel, the columns of ITS super-panel only (K = 256, a lower trapezoid);
+//     far     after a super-panel, everything to its right, once, with K = S (where most of the N^3/3 flops run,
+//             at the long K the tile engine likes).  From n_total = 8192 on the far update is split by tile column:
+//     F0      the next super-panel's columns, on the caller's (high-priority) stream, and
+//     F1      the rest, on a stream whose CU mask leaves 32 CUs alone: the next super-panel's panel chain (135 KB
+//             of LDS per workgroup, so it needs whole CUs) runs beside F1 on the CUs F1 cannot occupy.
+//   trail_kernel   persistent form of the near update (one stream of K-steps per workgroup).
+// Rows [id0, id1) may be declared an identity block (analytic gradients: cholesky_padded's hint): panel and update
+// workgroups whose rows are still structurally zero in the columns at hand leave at once.
 #include <climits>
 #include <type_traits>
 
@@ -99,13 +109,15 @@ __device__ __forceinline__ double rsqrt_t(double x) { return 1.0 / sqrt(x); }
 //   workgroup re-factors the diagonal block (redundant, but it removes the potrf -> trsm launch
 //   dependency and needs no explicit inverse).
 // Algorithm: left-looking over micro-panels of MP = 8 columns, one thread per row.
-//   1. each thread pulls its 8 entries into registers and subtracts the contribution of all
-//      finished columns (dot products with the 8 pivot rows: 16-byte LDS reads, pivot rows broadcast);
+//   0. at every 16-column boundary the block's columns are brought up to date with all finished columns by
+//      MFMAs that read both operands from the LDS image (16x16 tiles, 4 row tiles per wave);
+//   1. each thread pulls its 8 entries into registers and subtracts the contribution of the (at most 8)
+//      finished columns of the current 16-column block (16-byte LDS reads, pivot rows broadcast);
 //   2. the 8 pivot rows publish their updated 8x8 diagonal micro-block; barrier;
 //   3. every thread factors that 8x8 block redundantly in registers and runs the 8-step
 //      triangular solve on its own 8 values (for a pivot row this reproduces its row of L,
 //      diagonal included: d * rsqrt(d) = sqrt(d)); writes them back; barrier.
-// 2 barriers per micro-panel (32 per sub-panel) instead of 2 per column.
+// 2 barriers per micro-panel (32 per sub-panel, + 7 for the MFMA blocks) instead of 2 per column.
 // prefactored != 0: the diagonal block already holds L (solve only; used by smn_trsm).
 template <typename T>
 __global__ void __launch_bounds__(PanelCfg<T>::THREADS) panel_kernel(T* __restrict__ a, int64_t lda, int64_t j0,
