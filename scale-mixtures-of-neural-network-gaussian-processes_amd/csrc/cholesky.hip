@@ -384,21 +384,54 @@ __device__ __forceinline__ void upd_decode(const UpdArgs<T>& u, int tl, int& tr,
   }
 }
 
+// The same enumerations with 64-row tiles (128 columns): tile row r64 of the lower triangle owns the column tiles
+// 0 .. r64/2, so tile-row PAIR t holds 2 (t + 1) tiles and starts at linear index t (t + 1).
+template <typename T>
+__device__ __forceinline__ void upd_decode_half(const UpdArgs<T>& u, int tl, int& r64, int& tc) {
+  auto tri = [](int l, int& r, int& c) {
+    int t = (int)((sqrt(4.0 * (double)l + 1.0) - 1.0) * 0.5);
+    while ((t + 1) * (t + 2) <= l) ++t;
+    while (t * (t + 1) > l) --t;
+    const int rem = l - t * (t + 1);
+    r = 2 * t + rem / (t + 1);
+    c = rem % (t + 1);
+  };
+  if (u.lower == 1) {
+    tri(tl, r64, tc);
+  } else if (u.lower == 2) {
+    const int ntri = u.tiles_n * (u.tiles_n + 1);
+    if (tl < ntri) {
+      tri(tl, r64, tc);
+    } else {
+      r64 = 2 * u.tiles_n + (tl - ntri) / u.tiles_n;
+      tc = (tl - ntri) % u.tiles_n;
+    }
+  } else {
+    r64 = tl / u.tiles_n;
+    tc = tl % u.tiles_n;
+  }
+}
+
 // TAG only separates the two uses into two symbols (0: strip update, 1: trailing update) so that
 // rocprofv3 --stats reports them on separate lines.
-template <typename T, int TAG>
-__global__ void __launch_bounds__(256, sizeof(T) == 8 ? 1 : 2) update_kernel(UpdArgs<T> u) {
+// BM = 128: the 128x128 tile of every large launch.  BM = 64: half-height tiles for launches too small to fill the
+// chip with 128x128 ones (the near / F0 updates of the late, chain-bound super-panels): twice the workgroups, each
+// done in half the time.
+template <typename T, int TAG, int BM = kTile>
+__global__ void __launch_bounds__(256, sizeof(T) == 8 ? 1 : (BM == 64 ? 3 : 2)) update_kernel(UpdArgs<T> u) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  using Tile = MainTile<T>;
+  using Tile = TileNT<T, BM, kTile, SMN_STAGES>;
   using M = typename Tile::M;
   int tr, tc;
-  if (u.use_map) {
+  if (BM == 64) {
+    upd_decode_half(u, (int)blockIdx.x, tr, tc);
+  } else if (u.use_map) {
     if (!u.map.decode(blockIdx.x, tr, tc)) return;   // padding slot of a patch (uniform per workgroup)
   } else {
     upd_decode(u, (int)blockIdx.x, tr, tc);
   }
-  const int64_t row0 = u.r0 + (int64_t)tr * kTile, col0 = u.c0 + (int64_t)tc * kTile;
-  if (u.id0 >= 0 && row0 >= u.id0 && row0 + kTile <= u.id1 && row0 - u.id0 >= u.k0 + u.K) return;
+  const int64_t row0 = u.r0 + (int64_t)tr * BM, col0 = u.c0 + (int64_t)tc * kTile;
+  if (u.id0 >= 0 && row0 >= u.id0 && row0 + BM <= u.id1 && row0 - u.id0 >= u.k0 + u.K) return;
   Tile t;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wr = wave >> 1, wc = wave & 1;
@@ -593,6 +626,17 @@ int launch_update(smn_ctx* ctx, hipStream_t st, T* a, int64_t lda, int64_t r0, i
       return SMN_OK;
     }
   }
+  if (tag == 1 && !u.use_map && nt <= ctx->half_tile_max) {
+    // too few 128x128 tiles to fill the chip: 64-row tiles, twice as many workgroups
+    const int64_t nh = lower == 1   ? tiles_m * (tiles_m + 1)
+                       : lower == 2 ? tiles_n * (tiles_n + 1) + 2 * (tiles_m - tiles_n) * tiles_n
+                                    : 2 * tiles_m * tiles_n;
+    ProfScope ps(ctx, PROF_TRAIL, st);
+    auto kern = update_kernel<T, 1, 64>;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nh), dim3(256), (TileNT<T, 64, kTile, SMN_STAGES>::LDS_BYTES), st, u);
+    SMN_CHECK_LAUNCH(ctx);
+    return SMN_OK;
+  }
   {
     ProfScope ps(ctx, tag ? PROF_TRAIL : PROF_STRIP, st);
     if (tag) {
@@ -638,6 +682,9 @@ int set_lds_attrs(smn_ctx* ctx) {
   SMN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(update_kernel<T, 1>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)MainTile<T>::LDS_BYTES));
+  SMN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(update_kernel<T, 1, 64>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)(TileNT<T, 64, kTile, SMN_STAGES>::LDS_BYTES)));
   if constexpr (sizeof(T) == 4)
     SMN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(trail_kernel<T>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize,

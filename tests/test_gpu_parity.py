@@ -403,6 +403,8 @@ def test_cholesky_more_workgroups_than_cus_and_lookahead(L, ctx, dtype, n, m):
     {"SMN_PERSIST_MAXK": "1024"},
     {"SMN_SUPER": "2048"},
     {"SMN_XCD_MAP": "1"},
+    {"SMN_HALF_TILES": "0"},                                   # no 64-row tiles for the small launches
+    {"SMN_HALF_TILES": "100000"},                              # 64-row tiles everywhere
 ])
 def test_cholesky_schedule_variants_agree(L, env):
     """Every schedule the environment switches select factors the same matrix to the same result (the default
