@@ -626,14 +626,20 @@ int launch_update(smn_ctx* ctx, hipStream_t st, T* a, int64_t lda, int64_t r0, i
       return SMN_OK;
     }
   }
-  if (tag == 1 && !u.use_map && nt <= ctx->half_tile_max) {
+  if (!u.use_map && nt <= ctx->half_tile_max) {
     // too few 128x128 tiles to fill the chip: 64-row tiles, twice as many workgroups
     const int64_t nh = lower == 1   ? tiles_m * (tiles_m + 1)
                        : lower == 2 ? tiles_n * (tiles_n + 1) + 2 * (tiles_m - tiles_n) * tiles_n
                                     : 2 * tiles_m * tiles_n;
-    ProfScope ps(ctx, PROF_TRAIL, st);
-    auto kern = update_kernel<T, 1, 64>;
-    hipLaunchKernelGGL(kern, dim3((unsigned)nh), dim3(256), (TileNT<T, 64, kTile, SMN_STAGES>::LDS_BYTES), st, u);
+    ProfScope ps(ctx, tag ? PROF_TRAIL : PROF_STRIP, st);
+    constexpr size_t hlds = TileNT<T, 64, kTile, SMN_STAGES>::LDS_BYTES;
+    if (tag) {
+      auto kern = update_kernel<T, 1, 64>;
+      hipLaunchKernelGGL(kern, dim3((unsigned)nh), dim3(256), hlds, st, u);
+    } else {
+      auto kern = update_kernel<T, 0, 64>;
+      hipLaunchKernelGGL(kern, dim3((unsigned)nh), dim3(256), hlds, st, u);
+    }
     SMN_CHECK_LAUNCH(ctx);
     return SMN_OK;
   }
@@ -683,6 +689,9 @@ int set_lds_attrs(smn_ctx* ctx) {
                                    hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)MainTile<T>::LDS_BYTES));
   SMN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(update_kernel<T, 1, 64>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)(TileNT<T, 64, kTile, SMN_STAGES>::LDS_BYTES)));
+  SMN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(update_kernel<T, 0, 64>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)(TileNT<T, 64, kTile, SMN_STAGES>::LDS_BYTES)));
   if constexpr (sizeof(T) == 4)

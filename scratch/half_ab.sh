@@ -6,8 +6,6 @@ for l in sys.stdin:
     if l.startswith('{'):
         d=json.loads(l); r=d['roofline']; print(d['ms_per_step'], d['phases_ms'], d['result']['logpdf'])
     elif l: print(l[:300])"; }
-run SMN_HALF_TILES=0
-run SMN_HALF_TILES=256
 run SMN_HALF_TILES=384
-run SMN_HALF_TILES=512
-run SMN_HALF_TILES=768
+run SMN_HALF_TILES=0
+run SMN_HALF_TILES=384
