@@ -142,7 +142,13 @@ __global__ void __launch_bounds__(256, (NTK || sizeof(T) == 8) ? 1 : 2) build_ke
   const int64_t row0 = (int64_t)tr * kTile, col0 = (int64_t)tc * kTile;
   Tile t;
   t.zero();
-  t.mainloop(a.x1 + row0 * a.ld1, a.ld1, a.x2 + col0 * a.ld2, a.ld2, a.kp, smem);
+  // a tile of the augmented matrix with no valid row or no valid column is pure identity padding (the y-row tile
+  // row of SPR.loss): no Gram to compute, the store below writes the padding
+  auto no_valid = [&](int64_t o) {
+    return o >= a.nv0 && !(a.nv1 > 0 && o < a.aug0 + a.nv1 && o + kTile > a.aug0);
+  };
+  const bool dead = a.store_mode == STORE_PAD_IDENTITY && (no_valid(row0) || no_valid(col0));
+  t.mainloop(a.x1 + row0 * a.ld1, a.ld1, a.x2 + col0 * a.ld2, a.ld2, dead ? 0 : a.kp, smem);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
