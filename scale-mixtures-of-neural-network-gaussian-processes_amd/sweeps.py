@@ -64,6 +64,14 @@ def find_grid(x_train, y_train, x_test, y_test, y_mean=0.0, y_std=1.0, *, networ
     gnll = np.full((len(w_std_list), len(b_std_list), len(eps_list)), np.nan)
     tnll = np.full(gnll.shape + (len(alpha_list), len(beta_list)), np.nan)
     quad, logdet, info = C.c_double(), C.c_double(), C.c_int()
+    # find.py:165-170 redraws the Burr-XII sample inside the innermost loop with a FIXED random_state=101, i.e. the
+    # same numbers every time: draw once per (alpha, beta)
+    burr = {}
+    for a in alpha_list:
+        for bb in beta_list:
+            sample_q = scipy_stats.burr12.rvs(c=a, d=bb, loc=0., scale=1., size=num_samples, random_state=101)
+            burr[(a, bb)] = (sample_q, -(1 / 2) * n * np.log(sample_q),
+                             scipy_stats.burr12.pdf(sample_q, c=a, d=bb, loc=0., scale=1.))
     for i, w in enumerate(w_std_list):
         for j, b in enumerate(b_std_list):
             ctx.call("smn_recursion", code, _NET[network], act, num_hiddens, float(w), float(b), 1.0, k0.ptr, m, m, ldm,
@@ -86,9 +94,7 @@ def find_grid(x_train, y_train, x_test, y_test, y_mean=0.0, y_std=1.0, *, networ
                 minus_log_det = -0.5 * logdet.value
                 for ia, a in enumerate(alpha_list):
                     for ib, bb in enumerate(beta_list):
-                        sample_q = scipy_stats.burr12.rvs(c=a, d=bb, loc=0., scale=1., size=num_samples, random_state=101)
-                        minus_log_sigma = -(1 / 2) * n * np.log(sample_q)
-                        prob_prior = scipy_stats.burr12.pdf(sample_q, c=a, d=bb, loc=0., scale=1.)
+                        sample_q, minus_log_sigma, prob_prior = burr[(a, bb)]
                         prob_q = prob_prior
                         log_prob_data = minus_log_two_pi + minus_log_det + minus_quad / sample_q + minus_log_sigma
                         prob_data = np.exp(log_prob_data - log_prob_data.max())
