@@ -521,6 +521,28 @@ def test_predict_joint_and_fused(L, ctx, dtype, n, t, c):
     assert relerr(np.asarray(m2), rmean) < tol and relerr(np.asarray(c2), rcov) < tol
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("act", ["relu", "erf"])
+def test_predict_ntk_posterior(dtype, act):
+    """predict_fn(get='ntk') (sample.ipynb's use of gradient_descent_mse_ensemble) against the oracle's Appendix A.5."""
+    from smnngp import nt_kernels, predict
+    rng = np.random.default_rng(31)
+    n, t, d, eps = 260, 37, 7, 1e-2
+    x = rng.standard_normal((n, d)); xt = rng.standard_normal((t, d)); y = rng.standard_normal((n, 2))
+    kfn = nt_kernels.get_mlp_kernel(2, act=act, w_std=1.3, b_std=0.2, last_w_std=1.1)
+    pf = predict.gradient_descent_mse_ensemble(kfn, x.astype(dtype), y.astype(dtype), diag_reg=eps)
+    mean, cov = pf(x_test=xt.astype(dtype), get="ntk")
+    xa = np.concatenate([x, xt])
+    kj, tj = O.mlp_kernel(xa, None, 2, act, 1.3, 0.2, 1.1, ("nngp", "ntk"))
+    rmean, rcov = O.predict_ntk(kj[:n, :n], kj[n:, :n], kj[n:, n:], tj[:n, :n], tj[n:, :n], y, diag_reg=eps)
+    tol = 1e-7 if dtype == np.float64 else 1e-2
+    assert relerr(mean, rmean) < tol and relerr(cov, rcov) < tol
+    only_mean = pf(x_test=xt.astype(dtype), get="ntk", compute_cov=False)
+    assert relerr(only_mean, rmean) < tol
+    with pytest.raises(NotImplementedError):
+        pf(x_test=xt.astype(dtype), get="bogus")
+
+
 # ----------------------------------------------------------------------------- spax facade == the reference's call sequence
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("method", ["gp", "tp"])
