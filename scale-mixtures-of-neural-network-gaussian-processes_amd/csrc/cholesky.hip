@@ -47,13 +47,11 @@ struct PanelCfg;
 template <>
 struct PanelCfg<float> {
   static constexpr int XR = SMN_PANEL_XR;                     // appended rows per workgroup (multiple of 32)
-  static constexpr int THREADS = (PB + XR + 63) / 64 * 64;    // one thread per LDS row, whole waves
   static constexpr int LD = PB + 4;    // row stride (elements): 16-byte aligned rows, b128 reads conflict-free
 };
 template <>
 struct PanelCfg<double> {
   static constexpr int XR = 16;        // the 128 x 130 f64 diagonal block already takes 133 KB of LDS
-  static constexpr int THREADS = 192;
   static constexpr int LD = PB + 2;
 };
 // 16x16 MFMA tiles for the in-LDS block updates of the panel (operands read straight from the row-major LDS
@@ -88,9 +86,10 @@ struct PanelMma<double> {  // v_mfma_f64_16x16x4_f64
 };
 
 template <typename T>
-constexpr size_t panel_lds_bytes() {
-  return sizeof(T) * ((size_t)(PB + PanelCfg<T>::XR) * PanelCfg<T>::LD + MP * MP + PB);
+constexpr size_t panel_lds_bytes(int xr = PanelCfg<T>::XR) {
+  return sizeof(T) * ((size_t)(PB + xr) * PanelCfg<T>::LD + MP * MP + PB);
 }
+constexpr int panel_threads(int xr) { return (PB + xr + 63) / 64 * 64; }   // one thread per LDS row, whole waves
 
 #ifdef SMN_PANEL_TIMING   // debug build only: phase times of workgroup 0 of the first panel, printed by the kernel
 #define PT_DECL long long pt_t = wall_clock64(), pt_acc[6] = {0, 0, 0, 0, 0, 0}
@@ -119,14 +118,17 @@ __device__ __forceinline__ double rsqrt_t(double x) { return 1.0 / sqrt(x); }
 //      diagonal included: d * rsqrt(d) = sqrt(d)); writes them back; barrier.
 // 2 barriers per micro-panel (32 per sub-panel, + 7 for the MFMA blocks) instead of 2 per column.
 // prefactored != 0: the diagonal block already holds L (solve only; used by smn_trsm).
-template <typename T>
-__global__ void __launch_bounds__(PanelCfg<T>::THREADS) panel_kernel(T* __restrict__ a, int64_t lda, int64_t j0,
+// XRV = rows below the diagonal block carried per workgroup.  The default (128 in f32) minimises the number of
+// workgroups that each redo the diagonal factorisation; the f32 64-row form is launched when the panel has few
+// row blocks anyway (late, chain-bound super-panels): the MFMA block updates of a workgroup shrink by a quarter.
+template <typename T, int XRV = PanelCfg<T>::XR>
+__global__ void __launch_bounds__(panel_threads(XRV)) panel_kernel(T* __restrict__ a, int64_t lda, int64_t j0,
                                                                      int64_t rbeg, int64_t n_total, int prefactored,
                                                                      double* __restrict__ logdet,
                                                                      int* __restrict__ info, T* __restrict__ ldiag_out,
                                                                      int64_t id0, int64_t id1) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int XR = PanelCfg<T>::XR, NT = PanelCfg<T>::THREADS, LD = PanelCfg<T>::LD;
+  constexpr int XR = XRV, NT = panel_threads(XRV), LD = PanelCfg<T>::LD;
   constexpr int VEC = 16 / sizeof(T);
   using vec_t = typename Mfma<T>::vec_t;
   T* S = reinterpret_cast<T*>(smem);        // [PB + XR][LD]
@@ -657,22 +659,29 @@ int launch_update(smn_ctx* ctx, hipStream_t st, T* a, int64_t lda, int64_t r0, i
   return SMN_OK;
 }
 
-template <typename T>
-int launch_panel(smn_ctx* ctx, hipStream_t st, T* a, int64_t lda, int64_t j0, int64_t n_total, int prefactored) {
-  constexpr int XR = PanelCfg<T>::XR;
+template <typename T, int XRV>
+int launch_panel_x(smn_ctx* ctx, hipStream_t st, T* a, int64_t lda, int64_t j0, int64_t n_total, int prefactored) {
   const int64_t rbeg = j0 + PB;
   const int64_t below = n_total - rbeg;
-  const unsigned grid = below > 0 ? (unsigned)((below + XR - 1) / XR) : 1u;
-  const size_t lds = panel_lds_bytes<T>();
-  auto kern = panel_kernel<T>;
+  const unsigned grid = below > 0 ? (unsigned)((below + XRV - 1) / XRV) : 1u;
+  auto kern = panel_kernel<T, XRV>;
   {
     ProfScope ps(ctx, PROF_PANEL, st);
     T* ldiag = reinterpret_cast<T*>(ctx->ws[3]) + (j0 / PB) * (int64_t)(PB * PB);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(PanelCfg<T>::THREADS), lds, st, a, lda, j0, rbeg, n_total, prefactored,
-                       ctx->d_scal, ctx->d_info, ldiag, ctx->chol_id0, ctx->chol_id1);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(panel_threads(XRV)), panel_lds_bytes<T>(XRV), st, a, lda, j0, rbeg, n_total,
+                       prefactored, ctx->d_scal, ctx->d_info, ldiag, ctx->chol_id0, ctx->chol_id1);
   }
   SMN_CHECK_LAUNCH(ctx);
   return SMN_OK;
+}
+
+template <typename T>
+int launch_panel(smn_ctx* ctx, hipStream_t st, T* a, int64_t lda, int64_t j0, int64_t n_total, int prefactored) {
+  if constexpr (sizeof(T) == 4 && PanelCfg<T>::XR == 128) {
+    // few row blocks left: 64-row workgroups (twice as many, each with a quarter less MFMA work)
+    if (n_total - (j0 + PB) <= (int64_t)ctx->panel_small_rows) return launch_panel_x<T, 64>(ctx, st, a, lda, j0, n_total, prefactored);
+  }
+  return launch_panel_x<T, PanelCfg<T>::XR>(ctx, st, a, lda, j0, n_total, prefactored);
 }
 
 template <typename T>
@@ -682,6 +691,9 @@ int set_lds_attrs(smn_ctx* ctx) {
   SMN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(panel_kernel<T>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)panel_lds_bytes<T>()));
+  if constexpr (sizeof(T) == 4 && PanelCfg<T>::XR == 128)
+    SMN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(panel_kernel<T, 64>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)panel_lds_bytes<T>(64)));
   SMN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(update_kernel<T, 0>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)MainTile<T>::LDS_BYTES));
@@ -871,13 +883,13 @@ int solve_rows_padded(smn_ctx* ctx, int dtype, void* a, int64_t n_total, int64_t
     if (dtype == SMN_F64) {
       constexpr int XR = PanelCfg<double>::XR;
       const unsigned grid = (unsigned)((n_total - n_factor + XR - 1) / XR);
-      hipLaunchKernelGGL(panel_kernel<double>, dim3(grid), dim3(PanelCfg<double>::THREADS),
+      hipLaunchKernelGGL(panel_kernel<double>, dim3(grid), dim3(panel_threads(XR)),
                          panel_lds_bytes<double>(), st, static_cast<double*>(a), lda, js, n_factor,
                          n_total, 1, ctx->d_scal, ctx->d_info, static_cast<double*>(nullptr), (int64_t)-1, (int64_t)-1);
     } else {
       constexpr int XR = PanelCfg<float>::XR;
       const unsigned grid = (unsigned)((n_total - n_factor + XR - 1) / XR);
-      hipLaunchKernelGGL(panel_kernel<float>, dim3(grid), dim3(PanelCfg<float>::THREADS),
+      hipLaunchKernelGGL(panel_kernel<float>, dim3(grid), dim3(panel_threads(XR)),
                          panel_lds_bytes<float>(), st, static_cast<float*>(a), lda, js, n_factor,
                          n_total, 1, ctx->d_scal, ctx->d_info, static_cast<float*>(nullptr), (int64_t)-1, (int64_t)-1);
     }
