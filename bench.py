@@ -40,7 +40,7 @@ def parse():
     p.add_argument("--act", default="relu")
     p.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     p.add_argument("--eps", type=float, default=None)
-    p.add_argument("--cpu-sample-n", type=int, default=4096)
+    p.add_argument("--cpu-sample-n", type=int, default=12288)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-recursion-probe", action="store_true")
     p.add_argument("--no-exclusive-probe", action="store_true", help="skip the look-ahead-off pass that fills frac_exclusive")
