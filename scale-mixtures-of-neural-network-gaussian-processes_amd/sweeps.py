@@ -31,8 +31,10 @@ def _norm_logpdf(x, mean, sigma):
 def find_grid(x_train, y_train, x_test, y_test, y_mean=0.0, y_std=1.0, *, network="mlp", num_hiddens=4,
               activation="relu", w_std_list=(1.0, 1.4, 2.0), b_std_list=(0.0, 0.3, 1.0),
               eps_list=(1e-6, 1e-4, 1e-2), alpha_list=(1.0, 2.0, 3.0), beta_list=(1.0, 2.0, 3.0),
-              num_samples=1000, ctx=None):
-    """Returns dict(gnll[i,j,k], tnll[i,j,k,a,b], best_gaussian, best_student) — the tables find.py logs."""
+              num_samples=1000, ctx=None, workers=1):
+    """Returns dict(gnll[i,j,k], tnll[i,j,k,a,b], best_gaussian, best_student) — the tables find.py logs.
+    workers > 1 evaluates the (w_std, b_std) cells on that many host threads, each with its own context (streams and
+    workspaces) on the same GPU: UCI-sized kernels are latency-bound, so independent cells overlap almost freely."""
     from scipy import stats as scipy_stats       # host-only, same dependency as the reference's find.py
     from scipy.special import logsumexp
 
@@ -56,14 +58,10 @@ def find_grid(x_train, y_train, x_test, y_test, y_mean=0.0, y_std=1.0, *, networ
     k0 = ctx.empty((m, ldm), dt)
     q = ctx.empty((m,), dt)
     ctx.call("smn_gram", code, xa.ptr, m, d, None, 0, 0, d, k0.ptr, ldm, q.ptr, None)     # once per dataset
-    kj = ctx.empty((m, ldm), dt)
-    mean_d = ctx.empty((t, 1), dt)
-    cov_d = ctx.empty((t, t), dt)
     y_ = np.asarray(y_test, dtype=np.float64) * y_std + y_mean
     minus_log_two_pi = -(n / 2) * math.log(2 * math.pi)
     gnll = np.full((len(w_std_list), len(b_std_list), len(eps_list)), np.nan)
     tnll = np.full(gnll.shape + (len(alpha_list), len(beta_list)), np.nan)
-    quad, logdet, info = C.c_double(), C.c_double(), C.c_int()
     # find.py:165-170 redraws the Burr-XII sample inside the innermost loop with a FIXED random_state=101, i.e. the
     # same numbers every time: draw once per (alpha, beta)
     burr = {}
@@ -72,37 +70,83 @@ def find_grid(x_train, y_train, x_test, y_test, y_mean=0.0, y_std=1.0, *, networ
             sample_q = scipy_stats.burr12.rvs(c=a, d=bb, loc=0., scale=1., size=num_samples, random_state=101)
             burr[(a, bb)] = (sample_q, -(1 / 2) * n * np.log(sample_q),
                              scipy_stats.burr12.pdf(sample_q, c=a, d=bb, loc=0., scale=1.))
-    for i, w in enumerate(w_std_list):
-        for j, b in enumerate(b_std_list):
-            ctx.call("smn_recursion", code, _NET[network], act, num_hiddens, float(w), float(b), 1.0, k0.ptr, m, m, ldm,
-                     q.ptr, q.ptr, 1, _lib.GET_NNGP, kj.ptr, None, ldm)                       # once per (w, b)
-            for k, eps in enumerate(eps_list):
-                ctx.call("smn_predict", code, kj.ptr, n, t, ldm, yd.ptr, 1, float(eps), 0.0, mean_d.ptr, cov_d.ptr, t,
-                         None, None, C.byref(info))
-                if info.value:
-                    continue
-                mean_ = mean_d.numpy().astype(np.float64).ravel() * y_std + y_mean
-                cov = cov_d.numpy().astype(np.float64)
-                std_diag = np.sqrt(np.diag(cov))
-                gnll[i, j, k] = -np.mean(_norm_logpdf(y_, mean_, std_diag * y_std))         # find.py:50-55,145
-                # find.py:151-159 — y^T (K + eps I)^-1 y and log det, absolute eps, training block of kj
-                ctx.call("smn_lml", code, kj.ptr, n, ldm, yd.ptr, float(eps), 0.0, 1.0, None, C.byref(quad),
-                         C.byref(logdet), C.byref(info))
-                if info.value:
-                    continue
-                minus_quad = -0.5 * quad.value
-                minus_log_det = -0.5 * logdet.value
-                for ia, a in enumerate(alpha_list):
-                    for ib, bb in enumerate(beta_list):
-                        sample_q, minus_log_sigma, prob_prior = burr[(a, bb)]
-                        prob_q = prob_prior
-                        log_prob_data = minus_log_two_pi + minus_log_det + minus_quad / sample_q + minus_log_sigma
-                        prob_data = np.exp(log_prob_data - log_prob_data.max())
-                        wgt = prob_data * prob_prior / prob_q
-                        w_bar = wgt / np.sum(wgt)
-                        std = np.sqrt(sample_q[:, None]) * std_diag[None, :]
-                        log_probs = np.log(w_bar + 1e-24)[:, None] + _norm_logpdf(y_, mean_, std * y_std)
-                        tnll[i, j, k, ia, ib] = -np.mean(logsumexp(log_probs, axis=0))
+    ctx.synchronize()                          # K0, q, y are read by every worker's context from here on
+
+    class _Cell:                               # per-worker device buffers (K0 / q / y are shared, read-only)
+        def __init__(self, c):
+            self.ctx = c
+            self.kj = c.empty((m, ldm), dt)
+            self.mean_d = c.empty((t, 1), dt)
+            self.cov_d = c.empty((t, t), dt)
+
+    def eval_cell(cell, i, j):
+        c = cell.ctx
+        kj, mean_d, cov_d = cell.kj, cell.mean_d, cell.cov_d
+        quad, logdet, info = C.c_double(), C.c_double(), C.c_int()
+        w, b = w_std_list[i], b_std_list[j]
+        c.call("smn_recursion", code, _NET[network], act, num_hiddens, float(w), float(b), 1.0, k0.ptr, m, m, ldm,
+               q.ptr, q.ptr, 1, _lib.GET_NNGP, kj.ptr, None, ldm)                             # once per (w, b)
+        for k, eps in enumerate(eps_list):
+            c.call("smn_predict", code, kj.ptr, n, t, ldm, yd.ptr, 1, float(eps), 0.0, mean_d.ptr, cov_d.ptr, t,
+                   None, None, C.byref(info))
+            if info.value:
+                continue
+            mean_ = mean_d.numpy().astype(np.float64).ravel() * y_std + y_mean
+            cov = cov_d.numpy().astype(np.float64)
+            std_diag = np.sqrt(np.diag(cov))
+            gnll[i, j, k] = -np.mean(_norm_logpdf(y_, mean_, std_diag * y_std))             # find.py:50-55,145
+            # find.py:151-159 — y^T (K + eps I)^-1 y and log det, absolute eps, training block of kj
+            c.call("smn_lml", code, kj.ptr, n, ldm, yd.ptr, float(eps), 0.0, 1.0, None, C.byref(quad),
+                   C.byref(logdet), C.byref(info))
+            if info.value:
+                continue
+            minus_quad = -0.5 * quad.value
+            minus_log_det = -0.5 * logdet.value
+            for ia, a in enumerate(alpha_list):
+                for ib, bb in enumerate(beta_list):
+                    sample_q, minus_log_sigma, prob_prior = burr[(a, bb)]
+                    prob_q = prob_prior
+                    log_prob_data = minus_log_two_pi + minus_log_det + minus_quad / sample_q + minus_log_sigma
+                    prob_data = np.exp(log_prob_data - log_prob_data.max())
+                    wgt = prob_data * prob_prior / prob_q
+                    w_bar = wgt / np.sum(wgt)
+                    std = np.sqrt(sample_q[:, None]) * std_diag[None, :]
+                    log_probs = np.log(w_bar + 1e-24)[:, None] + _norm_logpdf(y_, mean_, std * y_std)
+                    tnll[i, j, k, ia, ib] = -np.mean(logsumexp(log_probs, axis=0))
+
+    cells = [(i, j) for i in range(len(w_std_list)) for j in range(len(b_std_list))]
+    workers = max(1, min(int(workers), len(cells)))
+    if workers == 1:
+        cell = _Cell(ctx)
+        for i, j in cells:
+            eval_cell(cell, i, j)
+    else:
+        import queue
+        import threading
+        todo = queue.Queue()
+        for ij in cells:
+            todo.put(ij)
+        errors = []
+
+        def run(wctx):
+            try:
+                cell = _Cell(wctx)
+                while True:
+                    try:
+                        i, j = todo.get_nowait()
+                    except queue.Empty:
+                        return
+                    eval_cell(cell, i, j)
+            except Exception as e:             # surfaced after the join
+                errors.append(e)
+
+        threads = [threading.Thread(target=run, args=(ctx if w == 0 else _lib.Context(ctx.device),)) for w in range(workers)]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+        if errors:
+            raise errors[0]
     out = dict(gnll=gnll, tnll=tnll, best_gaussian=None, best_student=None)
     if np.isfinite(gnll).any():
         i, j, k = np.unravel_index(np.nanargmin(gnll), gnll.shape)

@@ -641,6 +641,11 @@ def test_find_grid_matches_reference_formulas():
                         tn = -np.mean(logsumexp(lps, axis=0))
                         assert abs(got["tnll"][i, j, k, ia, ib] - tn) < 1e-6 * max(1, abs(tn)), (w, b, eps, a, be)
     assert got["best_gaussian"] is not None and got["best_student"] is not None
+    # the same grid on three host threads / three contexts of the same GPU: identical tables
+    got3 = sweeps.find_grid(x, y, xt, yt, 0.2, 1.3, network="mlp", num_hiddens=2, activation="relu", w_std_list=ws,
+                            b_std_list=bs, eps_list=es, alpha_list=als, beta_list=bes, workers=3)
+    assert np.array_equal(got3["gnll"], got["gnll"]) and np.array_equal(got3["tnll"], got["tnll"])
+    assert got3["best_student"] == got["best_student"]
 
 
 def test_finite_difference_train_step():
