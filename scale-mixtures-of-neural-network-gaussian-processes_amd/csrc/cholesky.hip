@@ -420,7 +420,7 @@ __device__ __forceinline__ void upd_decode_half(const UpdArgs<T>& u, int tl, int
 // chip with 128x128 ones (the near / F0 updates of the late, chain-bound super-panels): twice the workgroups, each
 // done in half the time.
 template <typename T, int TAG, int BM = kTile>
-__global__ void __launch_bounds__(256, sizeof(T) == 8 ? 1 : (BM == 64 ? 3 : 2)) update_kernel(UpdArgs<T> u) {
+__global__ void __launch_bounds__(256, BM == 64 ? (sizeof(T) == 8 ? 2 : 3) : 2) update_kernel(UpdArgs<T> u) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using Tile = TileNT<T, BM, kTile, SMN_STAGES>;
   using M = typename Tile::M;

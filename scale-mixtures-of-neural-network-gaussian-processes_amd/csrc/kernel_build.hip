@@ -107,7 +107,7 @@ struct BuildArgs {
 };
 
 template <typename T, int NET, int ACT, bool NTK>
-__global__ void __launch_bounds__(256, sizeof(T) == 8 ? 1 : 2) build_kernel(BuildArgs<T> a) {
+__global__ void __launch_bounds__(256, (sizeof(T) == 8 && NTK) ? 1 : 2) build_kernel(BuildArgs<T> a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using Tile = MainTile<T>;
   using M = typename Tile::M;
