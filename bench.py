@@ -132,7 +132,11 @@ def cpu_baseline(args, np_dtype, eps):
     # elementwise work over the host cores.  Same oracle functions, applied to row blocks on a thread pool (ufuncs
     # release the GIL); the Gram and the factorisation go to the multi-threaded BLAS/LAPACK as they stand.
     from concurrent.futures import ThreadPoolExecutor
-    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))       # the CPU share this process may really use
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 64))
     amap = O.get_act(args.act)
     t0 = time.perf_counter()
     k, q, _ = O.input_gram(x, None)
