@@ -439,6 +439,27 @@ def test_cholesky_schedule_variants_agree(L, env):
     assert relerr(f1[il], f0[il]) < 1e-4
 
 
+@pytest.mark.parametrize("dtype,n,m", [(np.float32, 9216, 128), (np.float64, 8192, 0)])
+def test_cholesky_lookahead_is_bitwise_reproducible(L, ctx, dtype, n, m):
+    """The look-ahead runs the far updates on a second stream beside the panel chain.  A missing dependency would
+    show as run-to-run differences: eight factorizations of the same matrix must agree bit for bit."""
+    rng = np.random.default_rng(8)
+    g = rng.standard_normal((n + m, 80)).astype(dtype)
+    a = (g @ g.T / 80 + np.diag(rng.uniform(1.0, 2.0, n + m))).astype(dtype)
+    first = None
+    for rep in range(8):
+        ad = ctx.to_device(a)
+        info, logdet = C.c_int(), C.c_double()
+        ctx.call("smn_cholesky", L.dtype_code(dtype), ad.ptr, n + m, n, n + m, 0, 0.0, 0.0, C.byref(info), C.byref(logdet))
+        got = ad.numpy()
+        assert info.value == 0
+        if first is None:
+            first = (got, logdet.value)
+        else:
+            il = np.tril_indices(n + m)
+            assert logdet.value == first[1] and np.array_equal(got[il], first[0][il]), rep
+
+
 def test_cholesky_shift_and_not_pd(L, ctx):
     rng = np.random.default_rng(11)
     n = 200
