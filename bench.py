@@ -221,17 +221,17 @@ def main():
     else:
         # Balanced symmetric shard (sharding.py, paired layout): rank r builds the lower trapezoids of row blocks
         # r and 2P-1-r packed into its chunk of `stage`, ONE in-place RCCL all-gather moves N^2/2-ish elements in
-        # total, an unpack kernel scatters them into K's lower triangle, and smn_lml (replicated) reads only that.
+        # total, smn_lml_from_blocks scatters them straight into the factorisation workspace and factors (replicated).
         from smnngp import sharding
         es = np.dtype(np_dtype).itemsize
         stage = ctx.empty((world * sharding.paired_chunk_elems(n, world),), np_dtype)
-        kfull = ctx.empty((n, n), np_dtype)
+        hblk = sharding.block_rows(n, world)
 
         def step():
             sharding.build_lower_sharded(ctx, code, es, L.NET_MLP, act, nl, 1.0, 1e-8, 1.0, x.ptr, n, d, d,
-                                         rank, world, stage.ptr, kfull.ptr, n)
-            ctx.call("smn_lml", code, kfull.ptr, n, n, y.ptr, eps, 0.0, 1.0, C.byref(lp), C.byref(quad),
-                     C.byref(logdet), C.byref(info))
+                                         rank, world, stage.ptr, None, 0)
+            ctx.call("smn_lml_from_blocks", code, stage.ptr, n, world, hblk, y.ptr, eps, 0.0, 1.0, C.byref(lp),
+                     C.byref(quad), C.byref(logdet), C.byref(info))
 
     def barrier():
         ctx.synchronize()

@@ -222,6 +222,11 @@ int smn_allgather(smn_ctx* ctx, int dtype, const void* send_d, void* recv_d, int
  * k_d [n,n] ld=ldk in natural row order. */
 int smn_unpack_lower_blocks(smn_ctx* ctx, int dtype, const void* stage_d, int64_t n, int nranks,
                             int64_t block_rows, void* k_d, int64_t ldk);
+/* smn_lml (same outputs, same likelihood arguments) fed from the gathered staging buffer: the blocks are
+ * scattered straight into the factorisation workspace, K is never assembled separately. */
+int smn_lml_from_blocks(smn_ctx* ctx, int dtype, const void* stage_d, int64_t n, int nranks,
+                        int64_t block_rows, const void* y_d, double eps_abs, double df, double scale,
+                        double* logpdf_h, double* quad_h, double* logdet_h, int* info_h);
 
 #ifdef __cplusplus
 }

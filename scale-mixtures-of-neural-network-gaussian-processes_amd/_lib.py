@@ -82,6 +82,7 @@ PROTOTYPES = {
     "smn_comm_destroy": [_vp],
     "smn_allgather": [_vp, _i, _vp, _vp, _i64],
     "smn_unpack_lower_blocks": [_vp, _i, _vp, _i64, _i, _i64, _vp, _i64],
+    "smn_lml_from_blocks": [_vp, _i, _vp, _i64, _i, _i64, _vp, _d, _d, _d, _pd, _pd, _pd, _pi],
 }
 for _name, _args in PROTOTYPES.items():
     _fn = getattr(_lib, _name)          # AttributeError here == a symbol the header declares is missing

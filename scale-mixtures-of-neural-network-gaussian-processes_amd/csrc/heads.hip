@@ -193,6 +193,30 @@ extern "C" int smn_lml(smn_ctx* ctx, int dtype, void* k_d, int64_t n, int64_t ld
   return SMN_OK;
 }
 
+// smn_lml fed straight from the gathered paired lower-block staging buffer (multi-GPU path): the blocks are
+// scattered into the factorisation workspace itself, so the assembled kernel is never materialised a second time.
+extern "C" int smn_lml_from_blocks(smn_ctx* ctx, int dtype, const void* stage_d, int64_t n, int nranks,
+                                   int64_t block_rows, const void* y_d, double eps_abs, double df, double scale,
+                                   double* logpdf_h, double* quad_h, double* logdet_h, int* info_h) {
+  if (!ctx || !stage_d || !y_d) return SMN_EINVAL;
+  if (dtype != SMN_F32 && dtype != SMN_F64) return smn_fail(ctx, SMN_EINVAL, "bad dtype");
+  if (n <= 0) return smn_fail(ctx, SMN_EINVAL, "smn_lml_from_blocks: empty");
+  if (df > 0.0 && !(scale > 0.0)) return smn_fail(ctx, SMN_EINVAL, "smn_lml_from_blocks: scale must be > 0");
+  Aug g;
+  SMN_TRY(aug_alloc(ctx, dtype, n, 0, 1, &g));
+  SMN_HIP(ctx, hipMemsetAsync(g.at(n, 0), 0, g.es * (size_t)(g.n_total - n) * (size_t)g.lda, ctx->stream));
+  SMN_TRY(smn_unpack_lower_blocks(ctx, dtype, stage_d, n, nranks, block_rows, g.a, g.lda));
+  SMN_TRY(fill_identity_pad(ctx, dtype, g.a, g.lda, g.n_pad, n));
+  double quad = 0.0, ld = 0.0;
+  int info = 0;
+  SMN_TRY(aug_finish(ctx, dtype, g, y_d, 1, n, eps_abs, 0.0, nullptr, nullptr, 0, &quad, &ld, &info));
+  if (logpdf_h) *logpdf_h = logpdf_from(quad, ld, n, df, scale, info);
+  if (quad_h) *quad_h = quad;
+  if (logdet_h) *logdet_h = ld;
+  if (info_h) *info_h = info;
+  return SMN_OK;
+}
+
 int predict_joint(smn_ctx* ctx, int dtype, void* kj_d, int64_t n, int64_t t, int64_t ldk, const void* y_d, int64_t c,
                   double ridge_rel, double ridge_abs, void* mean_d, void* cov_d, int64_t ldcov, double* quad_h,
                   double* logdet_h, int* info_h, bool td_identity) {

@@ -88,8 +88,9 @@ def block_offset(n: int, world: int, b: int):
 def build_lower_sharded(ctx, dtype_code, itemsize, net, act, num_hiddens, w_std, b_std, last_w_std,
                         x_ptr, n, ldx, d, rank, world, stage_ptr, k_ptr, ldk, get_nngp=1):
     """This rank's share of the symmetric NNGP build + the exchange: one smn_kernel_mlp_shard launch into the
-    rank's chunk of `stage_ptr` (world * paired_chunk_elems elements), one in-place smn_allgather, one
-    smn_unpack_lower_blocks into the lower triangle of k_ptr [n,n].  All on the context's stream."""
+    rank's chunk of `stage_ptr` (world * paired_chunk_elems elements), one in-place smn_allgather and, when k_ptr
+    is given, one smn_unpack_lower_blocks into the lower triangle of k_ptr [n,n] (pass None and hand the staging
+    buffer to smn_lml_from_blocks to skip the separate copy of K).  All on the context's stream."""
     import ctypes as C
     chunk = paired_chunk_elems(n, world)
     h = block_rows(n, world)
@@ -97,4 +98,5 @@ def build_lower_sharded(ctx, dtype_code, itemsize, net, act, num_hiddens, w_std,
     ctx.call("smn_kernel_mlp_shard", dtype_code, net, act, num_hiddens, w_std, b_std, last_w_std,
              x_ptr, n, ldx, d, world, rank, h, get_nngp, mine, None)
     ctx.call("smn_allgather", dtype_code, mine, stage_ptr, chunk)           # in place
-    ctx.call("smn_unpack_lower_blocks", dtype_code, stage_ptr, n, world, h, k_ptr, ldk)
+    if k_ptr is not None:
+        ctx.call("smn_unpack_lower_blocks", dtype_code, stage_ptr, n, world, h, k_ptr, ldk)

@@ -207,6 +207,11 @@ def test_paired_lower_block_shards_assemble_the_lower_triangle(L, ctx, dtype, n,
     ctx.call("smn_lml", code, k.ptr, n, n, y.ptr, eps, 0.0, 1.0, C.byref(lp), C.byref(quad), C.byref(logdet), C.byref(info))
     want = O.mvn_logpdf(yh.astype(np.float64), ref + eps * np.eye(n))
     assert info.value == 0 and abs(lp.value - want) < (2e-3 if dtype == np.float32 else 1e-8) * abs(want)
+    # the same likelihood straight from the staging buffer (no separate K): identical bits
+    lp2, q2, ld2, i2 = C.c_double(), C.c_double(), C.c_double(), C.c_int()
+    ctx.call("smn_lml_from_blocks", code, stage.ptr, n, world, S.block_rows(n, world), y.ptr, eps, 0.0, 1.0,
+             C.byref(lp2), C.byref(q2), C.byref(ld2), C.byref(i2))
+    assert i2.value == 0 and lp2.value == lp.value and q2.value == quad.value and ld2.value == logdet.value
 
 
 def test_build_lower_sharded_single_rank_and_bad_geometry(L, ctx):
