@@ -130,6 +130,15 @@ int smn_kernel_cnn(smn_ctx* ctx, int dtype, int act, int num_hiddens,
                    const void* x1_d, int64_t n1, const void* x2_d, int64_t n2,
                    int64_t H, int64_t W, int64_t C, int fill, void* nngp_d, int64_t ldk);
 
+/* Conv-ResNet NNGP kernel: experiments/nt_kernels.py:48-80 get_conv_resnet_kernel = WideResnet(block_size, k=1)
+ * without pooling: Conv; four groups of block_size residual blocks (strides 1,2,2,2; Conv shortcut in the first
+ * block of a group, Identity after; main path act, Conv(stride), act, Conv); Flatten; Dense(last_w_std).
+ * Same argument meaning as smn_kernel_cnn; H and W must be multiples of 8; block_size <= 6. */
+int smn_kernel_conv_resnet(smn_ctx* ctx, int dtype, int act, int block_size,
+                           double w_std, double b_std, double last_w_std,
+                           const void* x1_d, int64_t n1, const void* x2_d, int64_t n2,
+                           int64_t H, int64_t W, int64_t C, int fill, void* nngp_d, int64_t ldk);
+
 /* ---- factorisation and solves ----
  * smn_cholesky: in-place lower Cholesky of the leading n_factor x n_factor block of the symmetric
  * matrix a_d [n_total,n_total] (lower triangle read/written), carried through the remaining

@@ -377,3 +377,69 @@ def spr_loss_grad_fd(x, y, keys=("w_std", "b_std", "last_w_std", "eps", "alpha",
         dn = dict(kw); dn[k] = v - step
         out[k] = (spr_loss(x, y, **up) - spr_loss(x, y, **dn)) / (2.0 * step)
     return out
+
+
+# --------------------------------------------------------------------------
+# experiments/nt_kernels.py:48-80 — get_conv_resnet_kernel (WideResnet, k = 1, no pooling)
+# --------------------------------------------------------------------------
+def _conv3_same(a, stride):
+    """Kernel transform of stax.Conv(_, (3,3), strides=(s,s), padding='SAME') on the last two axes of a same-pixel
+    covariance map: the 3x3 zero-padded window SUM (the caller scales by w^2/9 and adds b^2).  SAME follows
+    lax.padtype_to_pads: out = ceil(in/s), pad_total = max((out-1) s + 3 - in, 0), pad_lo = pad_total // 2."""
+    h, w = a.shape[-2:]
+    oh, ow = -(-h // stride), -(-w // stride)
+    ph, pw = max((oh - 1) * stride + 3 - h, 0), max((ow - 1) * stride + 3 - w, 0)
+    pad = [(0, 0)] * (a.ndim - 2) + [(ph // 2, ph - ph // 2), (pw // 2, pw - pw // 2)]
+    ap = np.pad(a, pad)
+    out = np.zeros(a.shape[:-2] + (oh, ow), dtype=a.dtype)
+    for dy in range(3):
+        for dx in range(3):
+            out += ap[..., dy: dy + (oh - 1) * stride + 1: stride, dx: dx + (ow - 1) * stride + 1: stride]
+    return out
+
+
+def _act_maps(k, q1, q2, act):
+    """The per-pixel activation transform of cnn_kernel on (K [N,M,H,W], q1 [N,H,W], q2 [M,H,W])."""
+    if act == "relu":
+        p = q1[:, None] * q2[None, :]
+        sp = np.sqrt(p)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            cc = np.where(sp > 0, k / sp, 0.0)
+        ang = np.arccos(np.clip(cc, -1.0, 1.0))
+        return (np.sqrt(np.maximum(p - k * k, 0.0)) + (np.pi - ang) * k) / (2 * np.pi), q1 / 2.0, q2 / 2.0
+    if act == "erf":
+        p = (1 + 2 * q1)[:, None] * (1 + 2 * q2)[None, :]
+        kk = (2 / np.pi) * np.arcsin(np.clip(2 * k / np.sqrt(p), -1.0, 1.0))
+        return kk, (2 / np.pi) * np.arcsin(2 * q1 / (1 + 2 * q1)), (2 / np.pi) * np.arcsin(2 * q2 / (1 + 2 * q2))
+    raise KeyError("Unsupported act '{}'".format(act))
+
+
+def conv_resnet_kernel(x1, x2=None, num_hiddens=1, act="relu", w_std=1.0, b_std=0.0, last_w_std=1.0,
+                       dtype=np.float64):
+    """experiments/nt_kernels.py:48-80 — WideResnet(block_size=num_hiddens, k=1): Conv; four groups of residual
+    blocks (strides 1, 2, 2, 2; the first block of a group has a Conv shortcut, the others Identity; a block's main
+    path is act, Conv(stride), act, Conv); Flatten; Dense(last_w).  The AvgPool is commented out in the reference,
+    so only same-pixel covariances enter.  x [N,H,W,C].  NNGP only; small sizes only (documented NT behaviour)."""
+    x1 = np.asarray(x1, dtype=dtype)
+    sym = x2 is None
+    x2 = x1 if sym else np.asarray(x2, dtype=dtype)
+    c = x1.shape[-1]
+    w2, b2 = w_std ** 2, b_std ** 2
+    state = (np.einsum("nhwc,mhwc->nmhw", x1, x2) / c, np.einsum("nhwc,nhwc->nhw", x1, x1) / c,
+             np.einsum("mhwc,mhwc->mhw", x2, x2) / c)
+
+    def conv(st, stride):
+        return tuple(w2 * _conv3_same(a, stride) / 9.0 + b2 for a in st)
+
+    def block(st, stride, mismatch):
+        main = conv(_act_maps(*st, act), stride)
+        main = conv(_act_maps(*main, act), 1)
+        short = conv(st, stride) if mismatch else st
+        return tuple(m + s for m, s in zip(main, short))
+
+    state = conv(state, 1)
+    for stride in (1, 2, 2, 2):
+        state = block(state, stride, True)
+        for _ in range(num_hiddens - 1):
+            state = block(state, 1, False)
+    return (last_w_std ** 2 * state[0].mean(axis=(2, 3))).astype(dtype)

@@ -100,12 +100,14 @@ def get_dense_resnet_kernel(num_hiddens, num_class=1, act="relu", w_std=1., b_st
 
 
 class CnnKernelFn:
-    """kernel_fn of get_cnn_kernel (experiments/nt_kernels.py:34-45); x is [N,H,W,C]; NNGP only."""
+    """kernel_fn of get_cnn_kernel (experiments/nt_kernels.py:34-45) or, with entry="smn_kernel_conv_resnet", of
+    get_conv_resnet_kernel (:48-80, num_hiddens = block size); x is [N,H,W,C]; NNGP only."""
 
-    def __init__(self, num_hiddens, act, w_std, b_std, last_w_std, ctx=None):
+    def __init__(self, num_hiddens, act, w_std, b_std, last_w_std, ctx=None, entry="smn_kernel_cnn"):
         self.num_hiddens, self.act_name, self.act = int(num_hiddens), act, get_act_class(act)
         self.w_std, self.b_std, self.last_w_std = float(w_std), float(b_std), float(last_w_std)
         self.ctx = ctx
+        self.entry = entry
 
     def __call__(self, x1, x2=None, get="nngp", fill="full"):
         if get != "nngp":
@@ -122,7 +124,7 @@ class CnnKernelFn:
         n1, h, w, c = a.shape
         n2 = n1 if b is None else b.shape[0]
         k = ctx.empty((n1, n2), a.dtype)
-        ctx.call("smn_kernel_cnn", a.dcode, self.act, self.num_hiddens, self.w_std, self.b_std, self.last_w_std,
+        ctx.call(self.entry, a.dcode, self.act, self.num_hiddens, self.w_std, self.b_std, self.last_w_std,
                  a.ptr, n1, None if b is None else b.ptr, n2, h, w, c,
                  _lib.FILL_FULL if fill == "full" else _lib.FILL_LOWER, k.ptr, n2)
         return k
@@ -134,6 +136,6 @@ def get_cnn_kernel(num_hiddens, num_class=1, act="relu", w_std=1., b_std=0., las
 
 
 def get_conv_resnet_kernel(num_hiddens, num_class, act="relu", w_std=1., b_std=0., last_w_std=1.):
-    """experiments/nt_kernels.py:48-80 — strided WideResNet kernel; out of the hot-path scope."""
-    get_act_class(act)
-    raise NotImplementedError("get_conv_resnet_kernel is outside the accelerated path")
+    """experiments/nt_kernels.py:48-80 — WideResnet(block_size=num_hiddens, k=1) without pooling; x [N,H,W,C] with H, W
+    multiples of 8 (three stride-2 stages); NNGP only.  `num_class` does not enter the kernel."""
+    return CnnKernelFn(num_hiddens, act, w_std, b_std, last_w_std, entry="smn_kernel_conv_resnet")

@@ -308,6 +308,39 @@ def test_cnn_kernel(dtype, act, shape, layers):
         kfn(x, None, get="ntk")
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("act", ["relu", "erf"])
+@pytest.mark.parametrize("shape,block", [((6, 8, 8, 3), 1), ((5, 16, 8, 2), 2), ((3, 32, 32, 3), 1), ((4, 8, 24, 1), 3)])
+def test_conv_resnet_kernel(dtype, act, shape, block):
+    """get_conv_resnet_kernel (nt_kernels.py:48-80): WideResnet blocks with strided convolutions and Conv / Identity
+    shortcuts, symmetric and cross, square and non-square images, vs the oracle."""
+    from smnngp import nt_kernels
+    rng = np.random.default_rng(sum(shape) + block)
+    x = rng.standard_normal(shape).astype(dtype)
+    x2 = rng.standard_normal((3,) + shape[1:]).astype(dtype)
+    kfn = nt_kernels.get_conv_resnet_kernel(block, 10, act=act, w_std=1.2, b_std=0.3, last_w_std=0.9)
+    k = np.asarray(kfn(x, None, get="nngp"))
+    ref = O.conv_resnet_kernel(x.astype(np.float64), None, block, act, 1.2, 0.3, 0.9)
+    assert k.shape == (shape[0], shape[0]) and relerr(k, ref) < RTOL[dtype]
+    assert np.array_equal(k, k.T)
+    kc = np.asarray(kfn(x, x2, get="nngp"))
+    refc = O.conv_resnet_kernel(x.astype(np.float64), x2.astype(np.float64), block, act, 1.2, 0.3, 0.9)
+    assert kc.shape == (shape[0], 3) and relerr(kc, refc) < RTOL[dtype]
+
+
+def test_conv_resnet_kernel_rejects_what_it_cannot_do(L, ctx):
+    from smnngp import nt_kernels
+    kfn = nt_kernels.get_conv_resnet_kernel(1, 10)
+    with pytest.raises(L.SmnError):
+        kfn(np.zeros((2, 12, 12, 3)), None)                                   # 12 is not a multiple of 8
+    with pytest.raises(L.SmnError):
+        nt_kernels.get_conv_resnet_kernel(7, 10)(np.zeros((2, 8, 8, 3)), None)  # op list too long
+    with pytest.raises(KeyError):
+        nt_kernels.get_conv_resnet_kernel(1, 10, act="tanh")
+    with pytest.raises(NotImplementedError):
+        kfn(np.zeros((2, 8, 8, 3)), None, get="ntk")
+
+
 def test_cnn_kernel_feeds_the_same_inference_heads():
     """SVSP-style consumers (spax/models.py:38-43) and NNGPKernel.predict use the conv kernel through the
     generic kernel_fn path: joint kernel -> smn_predict."""
