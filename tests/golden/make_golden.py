@@ -72,6 +72,12 @@ def main():
     data["cnn/x"] = xi
     for act in ("relu", "erf"):
         data["cnn/k_" + act] = O.cnn_kernel(xi, None, 3, act, 1.3, 0.2, 0.9)
+    # conv-resnet (WideResnet) kernel, block sizes 1 and 2
+    xr = np.random.default_rng(12).standard_normal((5, 8, 16, 2))
+    data["resnet/x"] = xr
+    for act in ("relu", "erf"):
+        for bs in (1, 2):
+            data["resnet/k_%s_%d" % (act, bs)] = O.conv_resnet_kernel(xr, None, bs, act, 1.2, 0.3, 0.9)
     data["names"] = np.array(names)
     np.savez_compressed(OUT, **data)
     print("wrote %s: %d arrays, %.1f KB" % (OUT, len(data), os.path.getsize(OUT) / 1024))

@@ -58,6 +58,9 @@ def test_oracle_reproduces_golden_heads(gold):
         assert abs(O.spr_test_nll(x, y, xt, yt, 0.25, 1.5, **kw) - nll) < 1e-7 * max(1, abs(nll))
     for act in ("relu", "erf"):
         assert np.allclose(O.cnn_kernel(gold["cnn/x"], None, 3, act, 1.3, 0.2, 0.9), gold["cnn/k_" + act], rtol=1e-12)
+        for bs in (1, 2):
+            assert np.allclose(O.conv_resnet_kernel(gold["resnet/x"], None, bs, act, 1.2, 0.3, 0.9),
+                               gold["resnet/k_%s_%d" % (act, bs)], rtol=1e-12)
 
 
 # ----------------------------------------------------------------------------- GPU
@@ -102,3 +105,7 @@ def test_hip_cnn_matches_golden(gold):
     for act in ("relu", "erf"):
         k = np.asarray(nt_kernels.get_cnn_kernel(3, act=act, w_std=1.3, b_std=0.2, last_w_std=0.9)(gold["cnn/x"]))
         assert np.max(np.abs(k - gold["cnn/k_" + act])) < 1e-9 * np.max(np.abs(gold["cnn/k_" + act]))
+        for bs in (1, 2):
+            kr = np.asarray(nt_kernels.get_conv_resnet_kernel(bs, 10, act=act, w_std=1.2, b_std=0.3, last_w_std=0.9)(gold["resnet/x"]))
+            ref = gold["resnet/k_%s_%d" % (act, bs)]
+            assert np.max(np.abs(kr - ref)) < 1e-9 * np.max(np.abs(ref))
