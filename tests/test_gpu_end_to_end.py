@@ -1,6 +1,6 @@
 """The reference's regression run, end to end, on the device path: experiments/regression/train.py:126-215
 (model, train step, validation / checkpoint loop) followed by experiments/regression/test.py:38-134 (restore from
-the run directory, test NLL), on the offline-reproducible `syn-t` generator (data.py:229-236, seed 761)."""
+the run directory, test NLL), on the offline-reproducible `syn-normal` / `syn-t` generators (data.py:219-236, seeds 829 / 761)."""
 import math
 import os
 
@@ -12,27 +12,34 @@ pytestmark = pytest.mark.gpu
 from oracle import nngp_oracle as O  # noqa: E402  (test infrastructure only)
 
 
-def _syn_t(num=300):
-    rs = np.random.RandomState(761)
+def _dataset(name):
+    """experiments/regression/data.py:219-236 (the two generators that need no download), then the run's own
+    permute_dataset(seed=10) / split_dataset(0.8, 0.1, 0.1) with train statistics."""
+    if name == "syn-normal":
+        num, rs = 100, np.random.RandomState(829)
+        noise = lambda: rs.standard_normal(size=num) * 0.2
+    else:
+        num, rs = 300, np.random.RandomState(761)
+        noise = lambda: rs.standard_t(df=1, size=num) * 0.8
     x = np.linspace(-num / 2, num / 2, num)[:, None]
     cov = np.exp(-0.5 * (x - x.T) ** 2)
-    y = rs.multivariate_normal(mean=np.zeros(num), cov=cov, size=1).flatten() + rs.standard_t(df=1, size=num) * 0.8
-    idx = np.random.RandomState(10).permutation(num)                 # permute_dataset(seed=10)
+    y = rs.multivariate_normal(mean=np.zeros(num), cov=cov, size=1).flatten() + noise()
+    idx = np.random.RandomState(10).permutation(num)
     x, y = x[idx], y[idx]
-    ntr, nva = int(0.8 * num), int(0.1 * num)                          # split_dataset(0.8, 0.1, 0.1)
+    ntr, nva = int(0.8 * num), int(0.1 * num)
     xm, xs, ym, ys = x[:ntr].mean(0), x[:ntr].std(0), y[:ntr].mean(), y[:ntr].std()
     std = lambda a, b: ((a - xm) / xs, (b - ym) / ys)
     return std(x[:ntr], y[:ntr]), std(x[ntr:ntr + nva], y[ntr:ntr + nva]), std(x[ntr + nva:], y[ntr + nva:]), (ym, ys)
 
 
-@pytest.mark.parametrize("method", ["gp", "tp"])
-def test_regression_run_train_checkpoint_restore(tmp_path, method):
+@pytest.mark.parametrize("data_name,method", [("syn-t", "gp"), ("syn-t", "tp"), ("syn-normal", "gp"), ("syn-normal", "tp")])
+def test_regression_run_train_checkpoint_restore(tmp_path, data_name, method):
     from smnngp import checkpoint, nt_kernels, train
     from smnngp.spax.kernels import NNGPKernel
     from smnngp.spax.likelihoods import GaussianLikelihood, StudentTLikelihood
     from smnngp.spax.models import SPR
-    (xtr, ytr), (xva, yva), (xte, yte), (ym, ys) = _syn_t()
-    args = dict(method=method, network="mlp", num_hiddens=2, activation="relu", data_name="syn-t", last_w_std=1.0)
+    (xtr, ytr), (xva, yva), (xte, yte), (ym, ys) = _dataset(data_name)
+    args = dict(method=method, network="mlp", num_hiddens=2, activation="relu", data_name=data_name, last_w_std=1.0)
 
     def get_kernel_fn(w_std, b_std, last_w_std):
         return nt_kernels.get_mlp_kernel(args["num_hiddens"], act=args["activation"], w_std=w_std, b_std=b_std,
