@@ -729,10 +729,10 @@ int cholesky_t(smn_ctx* ctx, T* a, int64_t n_total, int64_t n_factor, int64_t ld
                        n_shift, jitter_abs, ridge_rel, ctx->d_scal + 1);
   }
   SMN_CHECK_LAUNCH(ctx);
-  // Optional look-ahead (ctx->lookahead): the panel chain of outer panel J+1 runs on stream2 beside the
-  // bulk of trailing update J; update J is then split into T0 (the two tile columns panel J+1 lives in)
-  // and T_rest, and stream2 waits for T0 only.  Off by default: with 135 KB of LDS a panel workgroup
-  // cannot share a CU with the two resident update workgroups, so today the chain just queues.
+  // Older, one-level look-ahead (ctx->lookahead, SMN_LOOKAHEAD=1; kept for comparison, see the schedule-variant
+  // test): the panel chain of outer panel J+1 runs on stream2 beside the bulk of trailing update J; update J is
+  // split into T0 (the two tile columns panel J+1 lives in) and T_rest, and stream2 waits for T0 only.  Slower
+  // than the default below even with the updates on the CU-masked stream (profiles/r01e_lookahead_ab_variants.txt).
   constexpr int64_t W = 2 * PB;
   const bool la = ctx->lookahead;
   // Two-level schedule (default): inside a super-panel of S columns the K = 256 updates touch only the

@@ -16,7 +16,7 @@
 struct smn_ctx {
   int device = 0;
   hipStream_t stream = nullptr;   // main stream (high priority): every public call is ordered on it
-  hipStream_t stream2 = nullptr;  // look-ahead stream of the Cholesky driver
+  hipStream_t stream2 = nullptr;  // chain stream of the older one-level look-ahead (SMN_LOOKAHEAD=1)
   hipStream_t stream_bulk = nullptr;  // CU-masked stream of the far updates: may not use the first chain_cus CUs
   int chain_cus = 32;                 // CUs kept free for the panel chain (env SMN_CHAIN_CUS; 0 = no look-ahead)
   int64_t chain_min_n = 8192;         // look-ahead only from this matrix size on (env SMN_CHAIN_MIN_N)
@@ -37,7 +37,7 @@ struct smn_ctx {
   std::vector<hipEvent_t> prof_ev;   // pool, used pairwise
   std::vector<int> prof_cat;         // category of pair i
   size_t prof_used = 0;              // events handed out
-  bool lookahead = false;            // Cholesky look-ahead on stream2 (env SMN_LOOKAHEAD=1)
+  bool lookahead = false;            // older one-level look-ahead on stream2 (env SMN_LOOKAHEAD=1); the default look-ahead is chain_cus above
   int num_cu = 256;                  // hipDeviceProp_t::multiProcessorCount
   int64_t super_panel = 1024;        // columns per super-panel of the two-level Cholesky (env SMN_SUPER; 0 = one level)
   // structural-zero hint for the factorisation in flight: appended rows [id0, id1) hold an identity block
