@@ -47,18 +47,23 @@ def main():
     likelihood = GaussianLikelihood() if method == "gp" else StudentTLikelihood(2.0, 2.0)
     model = SPR(kernel, likelihood, xtr, ytr, ym, ys, eps=1e-2)
     step = train.build_train_step(model)                              # analytic gradient + Adam
+    scheduler = train.PlateauSchedule(lr=0.03, factor=0.5, patience=2)
     run_dir = tempfile.mkdtemp(prefix="smnngp_run_")
     ck = checkpoint.Checkpointer(run_dir)
     checkpoint.save_meta(run_dir, args)
     print("[%5d] NLL: %.5f  TEST: %.5f" % (0, model.test_nll(xva, yva), model.test_nll(xte, yte)))
     for i in range(1, 301):
-        nll = step(0.03)
+        nll = step(scheduler.lr)
         if i % 50 == 0:
             valid, test = model.test_nll(xva, yva), model.test_nll(xte, yte)
             ws, bs, ls = kernel.get_params()
             mark = "  (saved)" if ck.step(i, valid, model.vars()) else ""
             print("[%5d] nll: %.5f  ws: %.4f  bs: %.3E  ls: %.4f  e: %.3E  NLL: %.5f  TEST: %.5f%s"
                   % (i, nll, ws, bs, ls, model.eps.safe_value, valid, test, mark))
+            if scheduler.step(valid):
+                print("LR reduced to %.6f" % scheduler.lr)
+                if scheduler.lr < 1e-3:
+                    break
     restored, _ = checkpoint.restore_spr(run_dir, xtr, ytr, ym, ys, dtype=np.float64)
     print("restored from %s (step %d): TEST NLL %.5f" % (run_dir, checkpoint.latest_index(run_dir), restored.test_nll(xte, yte)))
 

@@ -18,7 +18,7 @@ import numpy as np
 
 from .spax.base import TrainVar
 
-__all__ = ["train_vars", "value_and_grad", "value_and_grad_fd", "Adam", "build_train_step"]
+__all__ = ["train_vars", "value_and_grad", "value_and_grad_fd", "Adam", "PlateauSchedule", "build_train_step"]
 
 
 def train_vars(model):
@@ -95,3 +95,49 @@ def build_train_step(model, variables=None, optimizer=None, h=1e-4, method="auto
         return value
 
     return train_step
+
+
+class PlateauSchedule:
+    """Learning-rate decay on a validation plateau, with the interface the regression run uses
+    (experiments/regression/train.py:159,198,208-211; experiments/utils.py:153-231): `.lr` is the current rate,
+    `.step(metric)` records one validation result and returns True when it just cut the rate by `factor`.
+    A result counts as an improvement when it beats the best one by more than `threshold` (relative by default);
+    after more than `patience` results without improvement the rate is multiplied by `factor`, not below `min_lr`."""
+
+    def __init__(self, lr, mode="min", factor=0.1, patience=10, threshold=1e-4, threshold_mode="rel", min_lr=0.0,
+                 eps=1e-8):
+        if mode not in ("min", "max"):
+            raise ValueError("mode " + str(mode) + " is unknown!")
+        if threshold_mode not in ("rel", "abs"):
+            raise ValueError("threshold mode " + str(threshold_mode) + " is unknown!")
+        self.lr, self.factor, self.patience, self.min_lr, self.eps = float(lr), factor, patience, min_lr, eps
+        sign = 1.0 if mode == "min" else -1.0               # work on sign * metric: smaller is always better
+        if threshold_mode == "rel":
+            # min: a < best (1 - t);  max: a > best (1 + t)  <=>  -a < -best (1 + t)
+            self._margin = lambda best: best * (1.0 - sign * threshold)
+        else:
+            self._margin = lambda best: best - threshold
+        self._sign = sign
+        self._best = float("inf")
+        self.stale = 0
+        self.calls = 0
+
+    @property
+    def best(self):
+        return self._sign * self._best
+
+    def step(self, metric):
+        value = self._sign * float(metric)
+        self.calls += 1
+        if value < self._margin(self._best):
+            self._best, self.stale = value, 0
+            return False
+        self.stale += 1
+        if self.stale <= self.patience:
+            return False
+        self.stale = 0
+        lowered = max(self.lr * self.factor, self.min_lr)
+        if self.lr - lowered > self.eps:
+            self.lr = lowered
+        return True
+

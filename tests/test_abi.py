@@ -97,3 +97,22 @@ def test_digamma_and_bijector_derivatives():
             fd = (p(raw + h) - p(raw - h)) / (2 * h)
             assert abs(p.grad(raw) - fd) < 1e-8 * max(1.0, abs(fd))
 
+
+
+def test_plateau_schedule_follows_the_reference_semantics():
+    """train.PlateauSchedule against the behaviour of the scheduler the regression run uses (experiments/utils.py:153-231):
+    relative / absolute thresholds, min / max modes, patience counting, the floor and the eps guard."""
+    from smnngp.train import PlateauSchedule
+    s = PlateauSchedule(0.1, factor=0.5, patience=2)
+    out = [s.step(v) for v in (1.0, 0.99999, 0.9, 0.91, 0.92, 0.93, 0.5)]
+    #        best=1   no (rel 1e-4)  better  bad1  bad2  bad3>patience -> cut   better
+    assert out == [False, False, False, False, False, True, False] and abs(s.lr - 0.05) < 1e-15 and s.best == 0.5
+    m = PlateauSchedule(1.0, mode="max", factor=0.1, patience=0, threshold=0.1, threshold_mode="abs", min_lr=0.05)
+    assert [m.step(v) for v in (1.0, 1.05, 1.2, 1.2)] == [False, True, False, True] and abs(m.lr - 0.05) < 1e-15
+    assert m.step(0.0) and m.lr == 0.05                                  # already at the floor: reported, not lowered
+    inf = PlateauSchedule(1e-9, factor=0.5, patience=0, eps=1e-8)
+    inf.step(1.0); assert inf.step(2.0) and inf.lr == 1e-9               # a cut smaller than eps is not applied
+    with pytest.raises(ValueError):
+        PlateauSchedule(0.1, mode="down")
+    with pytest.raises(ValueError):
+        PlateauSchedule(0.1, threshold_mode="pct")
