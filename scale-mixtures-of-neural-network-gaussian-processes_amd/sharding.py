@@ -86,17 +86,25 @@ def block_offset(n: int, world: int, b: int):
 
 
 def build_lower_sharded(ctx, dtype_code, itemsize, net, act, num_hiddens, w_std, b_std, last_w_std,
-                        x_ptr, n, ldx, d, rank, world, stage_ptr, k_ptr, ldk, get_nngp=1):
-    """This rank's share of the symmetric NNGP build + the exchange: one smn_kernel_mlp_shard launch into the
+                        x_ptr, n, ldx, d, rank, world, stage_ptr, k_ptr, ldk, ntk_stage_ptr=None, ntk_ptr=None):
+    """This rank's share of the symmetric kernel build + the exchange: one smn_kernel_mlp_shard launch into the
     rank's chunk of `stage_ptr` (world * paired_chunk_elems elements), one in-place smn_allgather and, when k_ptr
     is given, one smn_unpack_lower_blocks into the lower triangle of k_ptr [n,n] (pass None and hand the staging
-    buffer to smn_lml_from_blocks to skip the separate copy of K).  All on the context's stream."""
+    buffer to smn_lml_from_blocks to skip the separate copy of K).  With `ntk_stage_ptr` (a second staging buffer of
+    the same size) the NTK is built, gathered and -- into ntk_ptr -- unpacked alongside (BASELINE config 5).
+    All on the context's stream."""
     import ctypes as C
     chunk = paired_chunk_elems(n, world)
     h = block_rows(n, world)
-    mine = C.c_void_p(stage_ptr.value + rank * chunk * itemsize)
+    off = rank * chunk * itemsize
+    mine = C.c_void_p(stage_ptr.value + off)
+    mine_t = C.c_void_p(ntk_stage_ptr.value + off) if ntk_stage_ptr is not None else None
     ctx.call("smn_kernel_mlp_shard", dtype_code, net, act, num_hiddens, w_std, b_std, last_w_std,
-             x_ptr, n, ldx, d, world, rank, h, get_nngp, mine, None)
+             x_ptr, n, ldx, d, world, rank, h, 1 | (2 if mine_t is not None else 0), mine, mine_t)
     ctx.call("smn_allgather", dtype_code, mine, stage_ptr, chunk)           # in place
+    if mine_t is not None:
+        ctx.call("smn_allgather", dtype_code, mine_t, ntk_stage_ptr, chunk)
     if k_ptr is not None:
         ctx.call("smn_unpack_lower_blocks", dtype_code, stage_ptr, n, world, h, k_ptr, ldk)
+    if mine_t is not None and ntk_ptr is not None:
+        ctx.call("smn_unpack_lower_blocks", dtype_code, ntk_stage_ptr, n, world, h, ntk_ptr, ldk)

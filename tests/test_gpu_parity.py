@@ -223,9 +223,15 @@ def test_build_lower_sharded_single_rank_and_bad_geometry(L, ctx):
     stage = ctx.empty((S.paired_chunk_elems(n, 1),), np.float64)
     k = ctx.to_device(np.zeros((n, n)))
     S.build_lower_sharded(ctx, L.F64, 8, L.NET_MLP, L.ACT["erf"], 3, 1.1, 0.2, 0.9, x.ptr, n, d, d, 0, 1, stage.ptr, k.ptr, n)
-    ref = O.mlp_kernel(xh, None, 3, "erf", 1.1, 0.2, 0.9)
+    ref, reft = O.mlp_kernel(xh, None, 3, "erf", 1.1, 0.2, 0.9, ("nngp", "ntk"))
     il = np.tril_indices(n)
     assert relerr(k.numpy()[il], ref[il]) < RTOL[np.float64]
+    # NNGP + NTK together (config 5's flow): a second staging buffer, both gathered and unpacked
+    stage_t = ctx.empty((S.paired_chunk_elems(n, 1),), np.float64)
+    k2 = ctx.to_device(np.zeros((n, n))); t2 = ctx.to_device(np.zeros((n, n)))
+    S.build_lower_sharded(ctx, L.F64, 8, L.NET_MLP, L.ACT["erf"], 3, 1.1, 0.2, 0.9, x.ptr, n, d, d, 0, 1, stage.ptr, k2.ptr, n,
+                          ntk_stage_ptr=stage_t.ptr, ntk_ptr=t2.ptr)
+    assert relerr(k2.numpy()[il], ref[il]) < RTOL[np.float64] and relerr(t2.numpy()[il], reft[il]) < 5 * RTOL[np.float64]
     with pytest.raises(L.SmnError):
         ctx.call("smn_unpack_lower_blocks", L.F64, stage.ptr, n, 1, 100, k.ptr, n)        # block_rows not a tile multiple
     with pytest.raises(L.SmnError):
