@@ -32,8 +32,8 @@ TILE = 128
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=5)
-    p.add_argument("--warmup", type=int, default=2)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=3)
     p.add_argument("--n", type=int, default=16384)
     p.add_argument("--d", type=int, default=3072)
     p.add_argument("--layers", type=int, default=4)
