@@ -686,7 +686,7 @@ int launch_panel(smn_ctx* ctx, hipStream_t st, T* a, int64_t lda, int64_t j0, in
 
 template <typename T>
 int set_lds_attrs(smn_ctx* ctx) {
-  static bool done = false;   // per dtype instantiation
+  bool& done = ctx->lds_attrs_done[sizeof(T) == 8 ? 1 : 0];   // per context (= per device) and dtype
   if (done) return SMN_OK;
   SMN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(panel_kernel<T>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize,
