@@ -368,11 +368,11 @@ def spr_test_nll(x, y, x_test, y_test, y_mean=0.0, y_std=1.0, *, kernel="mlp", n
 def spr_loss_grad_fd(x, y, keys=("w_std", "b_std", "last_w_std", "eps", "alpha", "beta"), h=1e-5, **kw):
     """d spr_loss / d (constrained hyper-parameter) by central differences in fp64 — the quantity
     objax.GradValues(model.loss, vars) differentiates (experiments/regression/train.py:61-67), before the
-    softplus chain rule.  Checker for the analytic gradient (csrc/grad.hip); step h is relative."""
+    softplus chain rule.  Checker for the analytic gradient (csrc/grad.hip); the step is h * |value|."""
     out = {}
     for k in keys:
         v = float(kw[k])
-        step = h * max(1.0, abs(v))
+        step = h * abs(v) if v != 0.0 else h          # relative: eps ~ 1e-3 needs a step far below 1e-5
         up = dict(kw); up[k] = v + step
         dn = dict(kw); dn[k] = v - step
         out[k] = (spr_loss(x, y, **up) - spr_loss(x, y, **dn)) / (2.0 * step)
