@@ -9,6 +9,7 @@ from smnngp.spax.kernels import NNGPKernel
 from smnngp.spax.likelihoods import GaussianLikelihood, StudentTLikelihood
 from smnngp.spax.models import SPR
 
+KINDS = sys.argv[3].split(",") if len(sys.argv) > 3 else ["kernel", "kernel", "heads", "grad", "cnn", "chol", "predict"]
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 budget = float(sys.argv[2]) if len(sys.argv) > 2 else 120.0
 rng = np.random.default_rng(seed)
@@ -22,14 +23,50 @@ while time.time() < t_end:
     case = None
     try:
         dt = [np.float32, np.float64][rng.integers(2)]
-        kind = rng.choice(["kernel", "kernel", "heads", "grad", "cnn"])
+        kind = rng.choice(KINDS)
         act = ["relu", "erf"][rng.integers(2)]
         net = ["mlp", "resnet"][rng.integers(2)]
         L = int(rng.integers(1, 6))
         w, b, lw = float(rng.uniform(0.5, 2.0)), float(rng.choice([0.0, 1e-8, 0.1, 0.5, 1.0])), float(rng.uniform(0.5, 1.5))
         fac = nt_kernels.get_mlp_kernel if net == "mlp" else nt_kernels.get_dense_resnet_kernel
         ofn = O.mlp_kernel if net == "mlp" else O.dense_resnet_kernel
-        if kind == "kernel":
+        if kind == "chol":
+            import ctypes as C, scipy.linalg as sla
+            from smnngp import _lib as LL
+            ctx = LL.default_context()
+            n, m = int(rng.integers(1, 1400)), int(rng.integers(0, 260))
+            case = (kind, dt.__name__, n, m)
+            g = rng.standard_normal((n + m, max(4, (n + m) // 3)))
+            a = g @ g.T / g.shape[1] + np.diag(rng.uniform(0.5, 1.5, n + m))
+            ad = ctx.to_device(a.astype(dt))
+            info, logdet = C.c_int(), C.c_double()
+            ctx.call("smn_cholesky", LL.dtype_code(dt), ad.ptr, n + m, n, n + m, 0, 0.0, 0.0, C.byref(info), C.byref(logdet))
+            gotm = ad.numpy().astype(np.float64)
+            l = np.linalg.cholesky(a[:n, :n])
+            errs = [rel(np.tril(gotm[:n, :n]), l), abs(logdet.value - 2 * np.log(np.diag(l)).sum()) / max(1.0, abs(logdet.value)), float(info.value)]
+            if m:
+                wmat = sla.solve_triangular(l, a[:n, n:], lower=True).T
+                errs += [rel(gotm[n:, :n], wmat), rel(np.tril(gotm[n:, n:]), np.tril(a[n:, n:] - wmat @ wmat.T))]
+            # trsm both ways on a few right-hand sides
+            r = int(rng.integers(1, 40))
+            bmat = rng.standard_normal((n, r))
+            ld = ctx.to_device(l.astype(dt)); bd = ctx.to_device(bmat.astype(dt))
+            ctx.call("smn_trsm", LL.dtype_code(dt), ld.ptr, n, n, bd.ptr, r, r, 0)
+            ctx.call("smn_trsm", LL.dtype_code(dt), ld.ptr, n, n, bd.ptr, r, r, 1)
+            errs.append(rel(bd.numpy(), sla.cho_solve((l, True), bmat)) / 10)
+        elif kind == "predict":
+            n, t, d, c = int(rng.integers(2, 500)), int(rng.integers(1, 200)), int(rng.integers(1, 30)), int(rng.integers(1, 5))
+            eps = float(rng.choice([1e-3, 1e-2, 1e-1])); b = max(b, 0.1)
+            case = (kind, dt.__name__, net, act, L, n, t, d, c, w, b, lw, eps)
+            x = rng.standard_normal((n, d)); y = rng.standard_normal((n, c)); xt = rng.standard_normal((t, d))
+            kfn = fac(L, act=act, w_std=w, b_std=b, last_w_std=lw)
+            pf = predict.gradient_descent_mse_ensemble(kfn, x.astype(dt), y.astype(dt), diag_reg=eps)
+            mean, cov = pf(x_test=xt.astype(dt))
+            kw = (L, act, w, b, lw)
+            rm, rc = O.predict(ofn(x, None, *kw), ofn(xt, x, *kw), ofn(xt, None, *kw), y, diag_reg=eps)
+            scale = 50 if dt == np.float32 else 1e3
+            errs = [rel(mean, rm) / scale, rel(cov, rc) / scale]
+        elif kind == "kernel":
             n, m, d = int(rng.integers(1, 600)), int(rng.integers(1, 300)), int(rng.integers(1, 200))
             case = (kind, dt.__name__, net, act, L, n, m, d, w, b, lw)
             x = rng.standard_normal((n, d)).astype(dt); x2 = rng.standard_normal((m, d)).astype(dt)
