@@ -75,6 +75,30 @@ def test_cross_kernel_and_zero_bias_defaults(dtype, act):
     assert relerr(k, O.mlp_kernel(x2.astype(np.float64), None, 2, act, 1.0, 1e-8, 1.0)) < RTOL[dtype]
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("act", ["relu", "erf"])
+@pytest.mark.parametrize("net", ["mlp", "resnet"])
+def test_zero_input_rows_with_zero_bias(dtype, act, net):
+    """q = 0 at every layer for an all-zero input when b_std = 0: the correlation K/sqrt(q q') is 0/0 there.  No NaN
+    may appear and the entries must be the oracle's (which defines that correlation as 0, like the reference's
+    safe division), symmetric and cross, NNGP and NTK."""
+    from smnngp import nt_kernels
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((130, 5)); x[3] = 0.0; x[129] = 0.0
+    x2 = rng.standard_normal((4, 5)); x2[1] = 0.0
+    fac = nt_kernels.get_mlp_kernel if net == "mlp" else nt_kernels.get_dense_resnet_kernel
+    of = O.mlp_kernel if net == "mlp" else O.dense_resnet_kernel
+    kfn = fac(3, act=act, w_std=1.3, b_std=0.0, last_w_std=1.0)
+    with np.errstate(all="ignore"):
+        rk, rt = of(x, None, 3, act, 1.3, 0.0, 1.0, ("nngp", "ntk"))
+        ck, ct = of(x, x2, 3, act, 1.3, 0.0, 1.0, ("nngp", "ntk"))
+    g = kfn(x.astype(dtype), None, get=("nngp", "ntk")); gc = kfn(x.astype(dtype), x2.astype(dtype), get=("nngp", "ntk"))
+    for got, ref, scale in ((g.nngp, rk, 1), (g.ntk, rt, 5), (gc.nngp, ck, 1), (gc.ntk, ct, 5)):
+        got = np.asarray(got, np.float64)
+        assert np.isfinite(ref).all() and np.isfinite(got).all()
+        assert relerr(got, ref) < RTOL[dtype] * scale
+
+
 def test_bad_arguments_raise(L, ctx):
     from smnngp import nt_kernels
     with pytest.raises(KeyError):
