@@ -235,3 +235,28 @@ def test_c3_conv_nngp_sampled_parity_and_student_t_lml_fp64(L, ctx):
     want = (-t * math.log1p(quad.value / 4.0) - 0.5 * n * math.log(4.0 * math.pi) + math.lgamma(t) - math.lgamma(2.0)
             - 0.5 * logdet.value)
     assert abs(lp.value - want) < 1e-10 * abs(want)
+
+
+# ----------------------------------------------------------------------------- beyond the configurations: N = 65536
+def test_n65536_fused_loss_and_sampled_rows(L, ctx):
+    """Four times C4's N (a 17 GB factorisation workspace): index arithmetic, tile counts and the look-ahead at a size no
+    configuration reaches; checked through the log-pdf identity and sampled kernel rows against the oracle."""
+    n, d, nl = 65536, 256, 2
+    rng = np.random.default_rng(7)
+    xh = rng.standard_normal((n, d)).astype(np.float32); yh = rng.standard_normal(n).astype(np.float32)
+    x = ctx.to_device(xh); y = ctx.to_device(yh)
+    lp, quad, logdet, info = C.c_double(), C.c_double(), C.c_double(), C.c_int()
+    ctx.call("smn_spr_loss", L.F32, L.NET_MLP, L.ACT["relu"], nl, 1.2, 0.3, 1.0, x.ptr, n, d, d, y.ptr, 1e-2, 0.0, 1.0,
+             C.byref(lp), C.byref(quad), C.byref(logdet), C.byref(info))
+    assert info.value == 0 and np.isfinite(lp.value) and quad.value > 0
+    assert abs(lp.value - (-0.5 * quad.value - 0.5 * n * np.log(2 * np.pi) - 0.5 * logdet.value)) < 1e-9 * abs(lp.value)
+    rows = np.sort(rng.choice(n, 8, replace=False))
+    out = ctx.empty((len(rows), n), np.float32)
+    for i, r in enumerate(rows):
+        ctx.call("smn_kernel_mlp_rows", L.F32, L.NET_MLP, L.ACT["relu"], nl, 1.2, 0.3, 1.0, x.ptr, n, d, d, int(r), int(r) + 1,
+                 L.GET_NNGP, C.c_void_p(out.ptr.value + i * n * 4), None, n)
+    x64 = xh.astype(np.float64)
+    ref = O.mlp_kernel(x64[rows], x64, nl, "relu", 1.2, 0.3, 1.0)
+    for i, r in enumerate(rows):
+        ref[i, r] = O.diag_recursion((x64[r] ** 2).sum() / d, nl, "relu", 1.2, 0.3, 1.0)
+    assert relerr(out.numpy(), ref) < 2e-3
