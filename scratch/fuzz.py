@@ -30,7 +30,28 @@ while time.time() < t_end:
         w, b, lw = float(rng.uniform(0.5, 2.0)), float(rng.choice([0.0, 1e-8, 0.1, 0.5, 1.0])), float(rng.uniform(0.5, 1.5))
         fac = nt_kernels.get_mlp_kernel if net == "mlp" else nt_kernels.get_dense_resnet_kernel
         ofn = O.mlp_kernel if net == "mlp" else O.dense_resnet_kernel
-        if kind == "chol":
+        if kind == "shard":
+            import ctypes as C
+            from smnngp import _lib as LL, sharding as S
+            ctx = LL.default_context()
+            n, d, world = int(rng.integers(1, 1800)), int(rng.integers(1, 60)), int(rng.integers(1, 9))
+            case = (kind, dt.__name__, net, act, L, n, d, world, w, b, lw)
+            xh = rng.standard_normal((n, d)).astype(dt)
+            x = ctx.to_device(xh)
+            code, es = LL.dtype_code(dt), np.dtype(dt).itemsize
+            chunk, h = S.paired_chunk_elems(n, world), S.block_rows(n, world)
+            stage = ctx.to_device(np.full(world * chunk, np.nan, dt)); st2 = ctx.to_device(np.full(world * chunk, np.nan, dt))
+            netc = LL.NET_MLP if net == "mlp" else LL.NET_DENSE_RESNET
+            for r in range(world):
+                ctx.call("smn_kernel_mlp_shard", code, netc, LL.ACT[act], L, w, b, lw, x.ptr, n, d, d, world, r, h, 3,
+                         C.c_void_p(stage.ptr.value + r * chunk * es), C.c_void_p(st2.ptr.value + r * chunk * es))
+            k = ctx.to_device(np.zeros((n, n), dt)); t2 = ctx.to_device(np.zeros((n, n), dt))
+            ctx.call("smn_unpack_lower_blocks", code, stage.ptr, n, world, h, k.ptr, n)
+            ctx.call("smn_unpack_lower_blocks", code, st2.ptr, n, world, h, t2.ptr, n)
+            rk, rt = ofn(xh.astype(np.float64), None, L, act, w, b, lw, ("nngp", "ntk"))
+            il = np.tril_indices(n)
+            errs = [rel(k.numpy()[il], rk[il]), rel(t2.numpy()[il], rt[il]) / 5]
+        elif kind == "chol":
             import ctypes as C, scipy.linalg as sla
             from smnngp import _lib as LL
             ctx = LL.default_context()
