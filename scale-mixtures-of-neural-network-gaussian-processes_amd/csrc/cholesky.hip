@@ -419,20 +419,30 @@ __device__ __forceinline__ void upd_decode_half(const UpdArgs<T>& u, int tl, int
 // BM = 128: the 128x128 tile of every large launch.  BM = 64: half-height tiles for launches too small to fill the
 // chip with 128x128 ones (the near / F0 updates of the late, chain-bound super-panels): twice the workgroups, each
 // done in half the time.
-template <typename T, int TAG, int BM = kTile>
-__global__ void __launch_bounds__(256, BM == 64 ? (sizeof(T) == 8 ? 2 : 3) : 2) update_kernel(UpdArgs<T> u) {
+// BN = 64 (with BM = 64): quarter tiles for the smallest launches (strips, and the near / F0 updates once fewer
+// than ~a CU's worth of 128x128 tiles per CU is left): four workgroups per 128x128 tile, a quarter of the time each.
+// The accumulation order over K of an element does not depend on the tile shape, so every form gives the same bits.
+template <typename T, int TAG, int BM = kTile, int BN = kTile>
+__global__ void __launch_bounds__(256, BN == 64 ? 4 : (BM == 64 ? (sizeof(T) == 8 ? 2 : 3) : 2)) update_kernel(UpdArgs<T> u) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  using Tile = TileNT<T, BM, kTile, SMN_STAGES>;
+  using Tile = TileNT<T, BM, BN, SMN_STAGES>;
   using M = typename Tile::M;
+  static_assert(BN == kTile || (BM == 64 && BN == 64), "tile shapes: 128x128, 64x128, 64x64");
   int tr, tc;
-  if (BM == 64) {
+  int64_t qr = 0, qc = 0;   // quarter-tile offset inside the 128x128 tile
+  if (BN == 64) {
+    upd_decode(u, (int)(blockIdx.x >> 2), tr, tc);
+    qr = (blockIdx.x & 2) ? 64 : 0;
+    qc = (blockIdx.x & 1) ? 64 : 0;
+    tr *= 2;                // row0 below multiplies by BM = 64
+  } else if (BM == 64) {
     upd_decode_half(u, (int)blockIdx.x, tr, tc);
   } else if (u.use_map) {
     if (!u.map.decode(blockIdx.x, tr, tc)) return;   // padding slot of a patch (uniform per workgroup)
   } else {
     upd_decode(u, (int)blockIdx.x, tr, tc);
   }
-  const int64_t row0 = u.r0 + (int64_t)tr * BM, col0 = u.c0 + (int64_t)tc * kTile;
+  const int64_t row0 = u.r0 + (int64_t)tr * BM + qr, col0 = u.c0 + (int64_t)tc * kTile + qc;
   if (u.id0 >= 0 && row0 >= u.id0 && row0 + BM <= u.id1 && row0 - u.id0 >= u.k0 + u.K) return;
   Tile t;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -627,6 +637,20 @@ int launch_update(smn_ctx* ctx, hipStream_t st, T* a, int64_t lda, int64_t r0, i
       SMN_CHECK_LAUNCH(ctx);
       return SMN_OK;
     }
+  }
+  if (!u.use_map && nt <= ctx->quarter_tile_max) {
+    // very few tiles (strips; near / F0 updates of the chain-bound tail): 64x64 tiles, four workgroups per tile
+    ProfScope ps(ctx, tag ? PROF_TRAIL : PROF_STRIP, st);
+    constexpr size_t qlds = TileNT<T, 64, 64, SMN_STAGES>::LDS_BYTES;
+    if (tag) {
+      auto kern = update_kernel<T, 1, 64, 64>;
+      hipLaunchKernelGGL(kern, dim3((unsigned)(4 * nt)), dim3(256), qlds, st, u);
+    } else {
+      auto kern = update_kernel<T, 0, 64, 64>;
+      hipLaunchKernelGGL(kern, dim3((unsigned)(4 * nt)), dim3(256), qlds, st, u);
+    }
+    SMN_CHECK_LAUNCH(ctx);
+    return SMN_OK;
   }
   if (!u.use_map && nt <= ctx->half_tile_max) {
     // too few 128x128 tiles to fill the chip: 64-row tiles, twice as many workgroups

@@ -473,6 +473,8 @@ def test_cholesky_more_workgroups_than_cus_and_lookahead(L, ctx, dtype, n, m):
     {"SMN_XCD_MAP": "1"},
     {"SMN_HALF_TILES": "0"},                                   # no 64-row tiles for the small launches
     {"SMN_HALF_TILES": "100000"},                              # 64-row tiles everywhere
+    {"SMN_QUARTER_TILES": "0"},                                # no 64x64 tiles for the smallest launches
+    {"SMN_QUARTER_TILES": "100000"},                           # 64x64 tiles everywhere
 ])
 def test_cholesky_schedule_variants_agree(L, env):
     """Every schedule the environment switches select factors the same matrix to the same result (the default
