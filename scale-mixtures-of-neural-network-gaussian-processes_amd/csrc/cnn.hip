@@ -101,24 +101,39 @@ struct PairArgs {
 
 constexpr int kMaxPix = 64;   // pixels per lane (H*W <= 4096)
 
-// 4 waves per workgroup, each wave walks its own list of image pairs: the two maps of a wave are private to it,
+// 4 waves per workgroup, each wave walks its own list of image pairs: the map of a wave is private to it,
 // LDS operations of one wave execute in order, so the layers need no workgroup barrier (only a compiler fence).
+// ONE padded map per wave: a lane keeps the values of its NP pixels in registers, publishes them to the map,
+// reads the 9 taps of each of its pixels and overwrites the registers; the next layer's publish is issued after
+// every tap read of this one (same wave, in-order LDS), so no second map is needed -- half the LDS of a ping-pong
+// pair, twice the waves per CU to cover the latency of the table loads and of the f64 chains.
 // NP = pixels per lane (compile-time bound): padded-map offsets are computed once per kernel, not per layer.
-template <typename T, int ACT, int NP, bool EXACT>   // EXACT: H*W == 64*NP, no per-pixel guards
-__global__ void __launch_bounds__(256) conv_pair_kernel(PairArgs<T> a) {
+// Lanes whose pixel index runs past H*W are not branched around: they load from a clamped (valid) pixel, publish to
+// a dummy slot behind the map whose 3x3 neighbourhood is also behind the map, and are dropped from the final sum
+// (EXACT: H*W == 64*NP, there are none).
+#ifndef SMN_CNN_OCC_F32
+#define SMN_CNN_OCC_F32 2   // f32 wants the registers (ILP over its pixels) more than the waves: 4 spills and loses 27 %
+#endif
+#ifndef SMN_CNN_OCC_F64
+#define SMN_CNN_OCC_F64 4   // workgroups per CU the f64 form is compiled for (128 VGPRs, 9 spilled doubles; 2 / 3: -6 %)
+#endif
+template <typename T, int ACT, int NP, bool EXACT>
+__global__ void __launch_bounds__(256, NP > 16 ? 1 : NP <= 4 ? 4 : !EXACT ? 2 : sizeof(T) == 8 ? SMN_CNN_OCC_F64 : SMN_CNN_OCC_F32)
+conv_pair_kernel(PairArgs<T> a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const ConvProg& p = a.prog;
   const int H = p.H, W = p.W, HW = H * W, PW = W + 2, PSZ = (H + 2) * PW;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  T* buf0 = reinterpret_cast<T*>(smem) + (size_t)wave * 2 * PSZ;
-  T* buf1 = buf0 + PSZ;
-  for (int i = lane; i < 2 * PSZ; i += 64) buf0[i] = T(0);   // halo stays zero for the whole kernel
-  int off[NP];                                               // centre of pixel lane + 64 i in the padded map
+  const int MSZ = PSZ + 2 * PW + 3;                     // map + the dummy slot's neighbourhood
+  T* map = reinterpret_cast<T*>(smem) + (size_t)wave * MSZ;
+  for (int i = lane; i < MSZ; i += 64) map[i] = T(0);   // halo stays zero for the whole kernel
+  int off[NP];                                          // centre of pixel lane + 64 i in the padded map
 #pragma unroll
   for (int i = 0; i < NP; ++i) {
     const int px = lane + 64 * i;
-    off[i] = (EXACT || px < HW) ? (px / W + 1) * PW + px % W + 1 : -1;
+    off[i] = (EXACT || px < HW) ? (px / W + 1) * PW + px % W + 1 : PSZ + PW + 1;
   }
+  auto pix = [&](int i) { return EXACT ? lane + 64 * i : min(lane + 64 * i, HW - 1); };   // pixel a lane loads from
   const T w2_9 = (T)(p.w2 / 9.0), b2 = (T)p.b2;
   const T inv_c = (T)(1.0 / p.C);
   const int64_t stride = (int64_t)gridDim.x * 4;
@@ -134,49 +149,56 @@ __global__ void __launch_bounds__(256) conv_pair_kernel(PairArgs<T> a) {
       n = pr / a.n2;
       m = pr % a.n2;
     }
-    __builtin_amdgcn_wave_barrier();   // the previous pair's reads of the maps are done (same wave, in order)
-    // K0 map
+    // K0 map: channel loop outside, pixel loop inside, so the 2 NP loads of one channel are in flight together
     const T* xa = a.x1 + n * HW * p.C;
     const T* xb = a.x2 + m * HW * p.C;
+    T val[NP];
 #pragma unroll
-    for (int i = 0; i < NP; ++i) {
-      if (!EXACT && off[i] < 0) continue;
-      const int px = lane + 64 * i;
-      T s = T(0);
-      for (int c = 0; c < p.C; ++c) s = fma(xa[px * p.C + c], xb[px * p.C + c], s);
-      buf0[off[i]] = s * inv_c;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    T* cur = buf0;
-    T* nxt = buf1;
-    for (int l = 0; l < p.layers; ++l) {
-      const int64_t t1 = (n * p.layers + l) * HW + lane, t2 = (m * p.layers + l) * HW + lane;
+    for (int i = 0; i < NP; ++i) val[i] = T(0);
+    for (int c = 0; c < p.C; ++c) {
 #pragma unroll
-      for (int i = 0; i < NP; ++i) {
-        if (!EXACT && off[i] < 0) continue;
-        const T rr = a.R1[t1 + 64 * i] * a.R2[t2 + 64 * i];
-        const T* c = cur + off[i];
-        const T bs = ((c[-PW - 1] + c[-PW]) + (c[-PW + 1] + c[-1])) + ((c[0] + c[1]) + (c[PW - 1] + c[PW])) + c[PW + 1];
-        const T kt = fma(w2_9, bs, b2);
-        T kn;
-        if (ACT == 0) {
-          const T ss = rr > T(0) ? T(1.0 / (2.0 * nngp::kPi)) * rcp_any<T>(rr) : T(0);
-          kn = nngp::relu_map<T, false>(kt, rr, ss).k;
-        } else {
-          kn = nngp::erf_map<T, false>(kt, rr, T(0)).k;
+      for (int i0 = 0; i0 < NP; i0 += 4) {   // 8 loads in flight per batch
+        T va[4], vb[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          va[j] = xa[pix(i0 + j) * p.C + c];
+          vb[j] = xb[pix(i0 + j) * p.C + c];
         }
-        nxt[off[i]] = kn;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) val[i0 + j] = fma(va[j], vb[j], val[i0 + j]);
+        __builtin_amdgcn_sched_barrier(0);
       }
+    }
+#pragma unroll
+    for (int i = 0; i < NP; ++i) val[i] *= inv_c;
+    for (int l = 0; l < p.layers; ++l) {
+      const T* r1 = a.R1 + (n * p.layers + l) * HW;
+      const T* r2 = a.R2 + (m * p.layers + l) * HW;
+      // publish this layer's input; the previous layer's tap reads were issued before (in-order LDS of one wave)
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
-      T* t = cur; cur = nxt; nxt = t;
+#pragma unroll
+      for (int i = 0; i < NP; ++i) map[off[i]] = val[i];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        const T rr = r1[pix(i)] * r2[pix(i)];
+        const T* c = map + off[i];
+        const T bs = ((c[-PW - 1] + c[-PW]) + (c[-PW + 1] + c[-1])) + ((c[0] + c[1]) + (c[PW - 1] + c[PW])) + c[PW + 1];
+        const T kt = fma(w2_9, bs, b2);
+        if (ACT == 0) {
+          const T ss = rr > T(0) ? T(1.0 / (2.0 * nngp::kPi)) * rcp_any<T>(rr) : T(0);
+          val[i] = nngp::relu_map<T, false>(kt, rr, ss).k;
+        } else {
+          val[i] = nngp::erf_map<T, false>(kt, rr, T(0)).k;
+        }
+      }
     }
     // Flatten (mean over pixels) + last Dense
     T s = T(0);
 #pragma unroll
-    for (int i = 0; i < NP; ++i)
-      if (EXACT || off[i] >= 0) s += cur[off[i]];
+    for (int i = 0; i < NP; ++i) s += (EXACT || lane + 64 * i < HW) ? val[i] : T(0);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     if (lane == 0) {
@@ -192,9 +214,7 @@ template <typename T, int ACT>
 int launch_pairs(smn_ctx* ctx, const PairArgs<T>& a, int64_t blocks, size_t lds, int64_t hw) {
 #define PAIR_CASE(NP)                                                                                              \
   if (hw <= 64 * NP) {                                                                                             \
-    /* the guard-free form pays in f64 (+9 %); in f32 it costs a wave of occupancy and 12 % (cnn_probe) */         \
-    auto kern = (hw == 64 * NP && sizeof(T) == 8) ? conv_pair_kernel<T, ACT, NP, true>                             \
-                                                  : conv_pair_kernel<T, ACT, NP, false>;                           \
+    auto kern = (hw == 64 * NP) ? conv_pair_kernel<T, ACT, NP, true> : conv_pair_kernel<T, ACT, NP, false>;        \
     SMN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
     ProfScope ps(ctx, PROF_BUILD, ctx->stream);                                                                    \
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, ctx->stream, a);                              \
@@ -216,7 +236,7 @@ int cnn_t(smn_ctx* ctx, int act, int layers, double w, double b, double lw, cons
   const int64_t HW = H * W;
   const size_t psz = (size_t)(H + 2) * (W + 2);
   const size_t lds_q = (2 * psz + 256) * sizeof(double);
-  const size_t lds_p = 4 * 2 * psz * sizeof(T);
+  const size_t lds_p = 4 * (psz + 2 * (W + 2) + 3) * sizeof(T);   // one padded map (+ dummy slot) per wave
   if (lds_q > 160 * 1024 || lds_p > 160 * 1024)
     return smn_fail(ctx, SMN_ENOTSUP, "smn_kernel_cnn: image %lldx%lld too large for the on-chip pair map", (long long)H, (long long)W);
   // tables: R1 [n1][L][HW], diag1 [n1] (+ R2, diag2)

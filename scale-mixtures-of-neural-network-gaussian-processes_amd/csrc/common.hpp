@@ -45,7 +45,7 @@ struct smn_ctx {
   int64_t chol_id0 = -1, chol_id1 = -1;
   bool lds_attrs_done[2] = {false, false};   // hipFuncSetAttribute(MaxDynamicSharedMemorySize) issued for f32 / f64 kernels
   int panel_small_rows = 4096;       // f32 panels with at most this many rows below use 64-row workgroups (env SMN_PANEL_SMALL)
-  int quarter_tile_max = 128;        // ... and with at most this many, 64x64 tiles (env SMN_QUARTER_TILES)
+  int quarter_tile_max = 256;        // ... and with at most this many, 64x64 tiles (env SMN_QUARTER_TILES)
   int half_tile_max = 384;           // trailing launches with at most this many 128x128 tiles use 64-row tiles (env SMN_HALF_TILES)
   int persist_max_k = 512;           // largest K the persistent trailing kernel takes (env SMN_PERSIST_MAXK)
   bool rec_sym = true;               // stand-alone recursion: lower-tile + mirror kernel when symmetric (env SMN_REC_SYM=0)

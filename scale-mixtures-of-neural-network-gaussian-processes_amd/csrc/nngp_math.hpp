@@ -102,10 +102,59 @@ __device__ __forceinline__ T clamp1(T c) {
   return fmin(fmax(c, T(-1)), T(1));
 }
 
+// J(c) = sqrt(1-c^2) + (pi - acos c) c in f64 with ONE square root and no division (NNGP-only paths):
+//   J(c) = (pi/2)(c + |c|) + d^(3/2) R(d),  d = 1 - |c|,  R(d) = (sqrt(2-d) - (1-d) acos(1-d)/sqrt(d)) / d
+// R is analytic on [0, 1] (nearest singularity d = 2, so the monomial terms decay like 2^-k and Horner in d is well
+// conditioned).  Degree-17 Chebyshev interpolant computed at 60 digits (scratch/relu_j_f64/fit.py); the f64 Horner form
+// against the exact J on 2e5 points of [-1, 1] (+ both end regions down to 1e-16): |error| <= 4.4e-16 (one ulp of pi),
+// relative error <= 3.9e-16 also where J -> 0 (c -> -1), because the form is a product there.  35 f64 instructions
+// against ~60 for the asin form above (two square roots, a rational and a Newton-refined reciprocal).
+__device__ __forceinline__ double relu_j_f64(double c) {
+  const double a = fabs(c);
+  const double d = 1.0 - a;
+  // sqrt(d) for d in [0, 1]: v_rsq_f64 seed + one coupled Goldschmidt step + one residual correction; the argument
+  // is kept off zero so no select is needed (d = 0 gives d * s = 0 below all the same)
+  const double dm = fmax(d, 1e-290);
+  const double y = __builtin_amdgcn_rsq(dm);
+  double g = dm * y, h = 0.5 * y;
+  const double e = fma(-h, g, 0.5);
+  g = fma(g, e, g);
+  h = fma(h, e, h);
+  g = fma(fma(-g, g, dm), h, g);
+  double r = 3.06589867858277351e-07;
+  r = fma(r, d, -2.07641508550871668e-06);
+  r = fma(r, d, 6.76505315467904507e-06);
+  r = fma(r, d, -1.34781210293057574e-05);
+  r = fma(r, d, 1.85191488354136423e-05);
+  r = fma(r, d, -1.79489152436826625e-05);
+  r = fma(r, d, 1.35345338816749084e-05);
+  r = fma(r, d, -6.11286061738224154e-06);
+  r = fma(r, d, 5.46578806810183682e-06);
+  r = fma(r, d, 5.83672864724229018e-06);
+  r = fma(r, d, 1.83491268408970555e-05);
+  r = fma(r, d, 5.10942545148346727e-05);
+  r = fma(r, d, 1.52114199372216396e-04);
+  r = fma(r, d, 4.88256075393192783e-04);
+  r = fma(r, d, 1.75373706836867010e-03);
+  r = fma(r, d, 7.57614408386195464e-03);
+  r = fma(r, d, 4.71404520791057768e-02);
+  r = fma(r, d, 9.42809041582063356e-01);
+  return fma(d * g, r, 1.57079632679489661923 * (c + a));
+}
+
+__device__ __forceinline__ float relu_j_fast(float c);   // the f32 counterpart, below
+
 // ReLU map.  kt = pre-activation covariance, rr = r_i r_j, ss = s_i s_j.
 template <typename T, bool WANT_DOT>
 __device__ __forceinline__ ActOut<T> relu_map(T kt, T rr, T ss) {
   const T c = clamp1(kt * rr);
+  if constexpr (!WANT_DOT) {   // NNGP only: the single-sqrt forms of J
+    ActOut<T> o;
+    if constexpr (sizeof(T) == 8) o.k = ss * relu_j_f64(c);
+    else o.k = ss * relu_j_fast(c);
+    o.kdot = T(0);
+    return o;
+  }
   const T a = fabs(c);
   const T c2 = c * c;
   const T as = asin_abs(a, c2);
