@@ -181,6 +181,12 @@ def main():
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
         args.gpus = world
 
+    multi = world > 1 or (args.sharded_path and "RANK" in os.environ and "MASTER_ADDR" in os.environ)
+    if multi:
+        # torch (host-side gloo rendezvous only) goes in FIRST: the wheel carries its own ROCm runtime and RCCL, and
+        # loaded in this order libsmnngp.so binds to that same runtime, so the process holds one HIP and one RCCL
+        import torch                               # noqa: F401
+        import torch.distributed                   # noqa: F401
     from smnngp import _lib as L
 
     np_dtype = np.float32 if args.dtype == "f32" else np.float64
@@ -191,7 +197,9 @@ def main():
     ctx = L.Context(local_rank)
 
     dist = None
-    if world > 1:
+    # `--sharded-path` under torch.distributed.run with ONE rank walks exactly the N>1 code (torch import, gloo
+    # rendezvous, broadcast of the RCCL id, communicator, all-gather) on a one-GPU box
+    if multi:
         import torch
         import torch.distributed as dist_mod
         dist = dist_mod
@@ -203,7 +211,7 @@ def main():
         dist.broadcast(t, 0)
         uid = C.create_string_buffer(bytes(t.tolist()), 128)
         ctx.call("smn_comm_init", world, rank, uid)
-    elif args.sharded_path:                        # 1-GPU rehearsal of the N>1 path: a real one-rank RCCL communicator
+    elif args.sharded_path:                        # plain `python bench.py --sharded-path`: one-rank communicator, no torch
         uid = C.create_string_buffer(128)
         assert L._lib.smn_comm_unique_id(uid) == 0, "RCCL unavailable"
         ctx.call("smn_comm_init", 1, 0, uid)

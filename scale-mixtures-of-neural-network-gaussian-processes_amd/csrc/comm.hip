@@ -3,6 +3,9 @@
 // libsmnngp.so never pay for it; the reference has no collective to mirror.
 #include <dlfcn.h>
 
+#include <string>
+#include <vector>
+
 #include "internal.hpp"
 
 namespace {
@@ -25,9 +28,30 @@ struct Rccl {
 Rccl& rccl() {
   static Rccl r;
   if (r.h) return r;
-  const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
-  for (const char* n : names) {
-    r.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+  // RCCL must sit on the SAME HIP runtime as this library (it is handed our streams and device pointers).  A
+  // process that also holds PyTorch can contain two ROCm stacks -- /opt/rocm's and the one inside the wheel
+  // (torch/lib/{libamdhip64,librccl}.so) -- and which libamdhip64 this library got bound to depends on the import
+  // order.  So: find the HIP runtime we are bound to and take the librccl that lives beside it (already loaded: that
+  // very object; otherwise a private, deep-bound copy, so its internal calls cannot land in another RCCL's global
+  // symbols -- that mix made ncclCommInitRank fail with "unhandled cuda error").
+  std::string dir;
+  Dl_info info;
+  if (dladdr(reinterpret_cast<void*>(&hipGetDeviceCount), &info) && info.dli_fname) {
+    dir = info.dli_fname;
+    const size_t slash = dir.rfind('/');
+    dir = slash == std::string::npos ? std::string() : dir.substr(0, slash + 1);
+  }
+  std::vector<std::string> names;
+  if (!dir.empty()) {
+    names.push_back(dir + "librccl.so.1");
+    names.push_back(dir + "librccl.so");
+  }
+  names.push_back("librccl.so.1");
+  names.push_back("librccl.so");
+  names.push_back("/opt/rocm/lib/librccl.so");
+  for (const std::string& n : names) {
+    r.h = dlopen(n.c_str(), RTLD_NOW | RTLD_NOLOAD);
+    if (!r.h) r.h = dlopen(n.c_str(), RTLD_NOW | RTLD_LOCAL | RTLD_DEEPBIND);
     if (r.h) break;
   }
   if (!r.h) return r;

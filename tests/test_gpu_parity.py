@@ -317,6 +317,32 @@ def test_rccl_single_rank_communicator_allgather(L):
     assert (b.numpy() == src).all()
 
 
+@pytest.mark.parametrize("torch_first", [True, False])
+def test_rccl_communicator_in_a_process_that_also_holds_torch(torch_first):
+    """bench.py's N>1 path imports torch (gloo rendezvous) in the process that then opens the RCCL communicator.
+    PyTorch's ROCm wheel carries its own librccl.so; comm.hip must use the copy already in the process (a second one
+    beside it made ncclCommInitRank fail).  Own process: the import order is the point."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    imports = ["import torch, torch.distributed", "from smnngp import _lib as L"]
+    if not torch_first:
+        imports.reverse()
+    code = "\n".join(["import sys, ctypes as C, numpy as np", "sys.path.insert(0, %r)" % root] + imports + [
+        "import torch",
+        "c = L.Context(0)",
+        "uid = C.create_string_buffer(128)",
+        "assert L._lib.smn_comm_unique_id(uid) == 0",
+        "c.call('smn_comm_init', 1, 0, uid)",
+        "src = np.arange(4096, dtype=np.float32)",
+        "a = c.to_device(src); b = c.to_device(np.zeros_like(src))",
+        "c.call('smn_allgather', L.F32, a.ptr, b.ptr, src.size)",
+        "assert (b.numpy() == src).all()",
+        "c.call('smn_comm_destroy')",
+        "print('ok')"])
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+
+
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("act", ["relu", "erf"])
 @pytest.mark.parametrize("shape,layers", [((7, 5, 4, 3), 2), ((9, 8, 8, 1), 4), ((5, 1, 1, 6), 3), ((3, 32, 32, 3), 1)])
