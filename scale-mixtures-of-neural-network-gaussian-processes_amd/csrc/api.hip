@@ -243,7 +243,9 @@ extern "C" int smn_ctx_create(int device_id, smn_ctx** out) {
             hipEventCreateWithFlags(&c->ev_b, hipEventDisableTiming) == hipSuccess &&
             hipEventCreate(&c->ev_t0) == hipSuccess && hipEventCreate(&c->ev_t1) == hipSuccess &&
             hipMalloc(reinterpret_cast<void**>(&c->d_scal), 64 * sizeof(double)) == hipSuccess &&
-            hipMalloc(reinterpret_cast<void**>(&c->d_info), 16 * sizeof(int)) == hipSuccess;
+            hipMalloc(reinterpret_cast<void**>(&c->d_info), 16 * sizeof(int)) == hipSuccess &&
+            hipHostMalloc(reinterpret_cast<void**>(&c->h_mail), 64 * sizeof(double), hipHostMallocMapped) == hipSuccess &&
+            hipHostGetDevicePointer(reinterpret_cast<void**>(&c->d_mail), c->h_mail, 0) == hipSuccess;
   if (!ok) {
     smn_ctx_destroy(c);
     return SMN_EHIP;
@@ -262,6 +264,7 @@ extern "C" int smn_ctx_destroy(smn_ctx* c) {
   for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
   if (c->d_scal) (void)hipFree(c->d_scal);
   if (c->d_info) (void)hipFree(c->d_info);
+  if (c->h_mail) (void)hipHostFree(c->h_mail);
   if (c->ev_a) (void)hipEventDestroy(c->ev_a);
   if (c->ev_b) (void)hipEventDestroy(c->ev_b);
   if (c->ev_t0) (void)hipEventDestroy(c->ev_t0);

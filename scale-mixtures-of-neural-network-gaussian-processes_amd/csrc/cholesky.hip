@@ -922,14 +922,32 @@ int solve_rows_padded(smn_ctx* ctx, int dtype, void* a, int64_t n_total, int64_t
   return SMN_OK;
 }
 
-int fetch_logdet_info(smn_ctx* ctx, double* logdet, int* info) {
-  double ld = 0.0;
-  int inf = 0;
-  SMN_HIP(ctx, hipMemcpyAsync(&ld, ctx->d_scal, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  SMN_HIP(ctx, hipMemcpyAsync(&inf, ctx->d_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+namespace {
+// mail[0] = logdet, mail[1] = info, mail[2 .. 2+nq) = the quadratic forms: written straight into pinned host memory
+__global__ void publish_kernel(const double* __restrict__ scal, const int* __restrict__ info,
+                               const double* __restrict__ quad, int nq, double* __restrict__ mail) {
+  const int t = threadIdx.x;
+  if (t == 0) mail[0] = scal[0];
+  if (t == 1) mail[1] = (double)info[0];
+  if (t < nq) mail[2 + t] = quad[t];
+}
+}  // namespace
+
+int fetch_results(smn_ctx* ctx, const double* quad_dev, int nq, double* quad_h, double* logdet, int* info) {
+  if (nq < 0 || nq > 62) return smn_fail(ctx, SMN_EINVAL, "fetch_results: %d values", nq);
+  hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->d_scal, ctx->d_info, quad_dev, nq,
+                     ctx->d_mail);
+  SMN_CHECK_LAUNCH(ctx);
   SMN_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const volatile double* m = ctx->h_mail;
+  int inf = (int)m[1];
   if (inf == INT_MAX) inf = 0;
-  if (logdet) *logdet = ld;
+  if (logdet) *logdet = m[0];
   if (info) *info = inf;
+  for (int i = 0; i < nq && quad_h; ++i) quad_h[i] = m[2 + i];
   return SMN_OK;
+}
+
+int fetch_logdet_info(smn_ctx* ctx, double* logdet, int* info) {
+  return fetch_results(ctx, nullptr, 0, nullptr, logdet, info);
 }

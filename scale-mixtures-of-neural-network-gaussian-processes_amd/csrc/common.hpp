@@ -29,6 +29,10 @@ struct smn_ctx {
   // small device scalar block: [0..15] doubles scratch, ints after
   double* d_scal = nullptr;   // 64 doubles
   int* d_info = nullptr;      // 16 ints
+  // pinned, device-mapped host mailbox: one tiny kernel publishes logdet / info / quadratic forms into it and the
+  // host reads them after ONE stream synchronisation (three pageable device-to-host copies cost ~0.1 ms per call)
+  double* h_mail = nullptr;   // 64 doubles, host pointer
+  double* d_mail = nullptr;   // the same memory as the device sees it
   void* comm = nullptr;       // ncclComm_t when smn_comm_init was called
   int nranks = 1, rank = 0;
   // per-kernel timing (smn_profile_*): hipEvent pairs around launches, resolved on read

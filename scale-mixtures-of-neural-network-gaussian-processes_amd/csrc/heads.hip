@@ -35,12 +35,6 @@ int aug_alloc(smn_ctx* ctx, int dtype, int64_t n, int64_t t, int64_t c, Aug* g) 
   return smn_workspace(ctx, 2, g->es * (size_t)g->n_total * (size_t)g->n_total, &g->a);
 }
 
-int fetch_doubles(smn_ctx* ctx, const double* dev, double* host, int n) {
-  SMN_HIP(ctx, hipMemcpyAsync(host, dev, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
-  SMN_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  return SMN_OK;
-}
-
 // Gaussian / multivariate-t log-pdf from (quad = y^T cov^-1 y, logdet = log det cov).
 double logpdf_from(double quad, double logdet, int64_t n, double df, double scale, int info) {
   if (info != 0 || std::isnan(quad) || std::isnan(logdet)) return std::nan("");
@@ -91,8 +85,7 @@ int aug_finish(smn_ctx* ctx, int dtype, const Aug& g, const void* y, int64_t ldy
   SMN_TRY(extract_posterior(ctx, dtype, g.a, g.lda, g.n_pad, g.t, g.c, mean, cov, ldcov, quad_dev));
   double ld = 0.0;
   int info = 0;
-  SMN_TRY(fetch_logdet_info(ctx, &ld, &info));
-  if (quad_h) SMN_TRY(fetch_doubles(ctx, quad_dev, quad_h, (int)g.c));
+  SMN_TRY(fetch_results(ctx, quad_dev, quad_h ? (int)g.c : 0, quad_h, &ld, &info));
   if (info != 0) {
     ld = std::nan("");
     if (quad_h)

@@ -52,6 +52,8 @@ int predict_joint(smn_ctx* ctx, int dtype, void* kj_d, int64_t n, int64_t t, int
                   double ridge_rel, double ridge_abs, void* mean_d, void* cov_d, int64_t ldcov, double* quad_h,
                   double* logdet_h, int* info_h, bool td_identity);
 int fetch_logdet_info(smn_ctx* ctx, double* logdet, int* info);
+// logdet, info and nq device doubles (quadratic forms) through the pinned mailbox: one tiny kernel + ONE synchronisation
+int fetch_results(smn_ctx* ctx, const double* quad_dev, int nq, double* quad_h, double* logdet, int* info);
 
 // small helpers implemented in util.hip
 int fill_identity_pad(smn_ctx* ctx, int dtype, void* a, int64_t lda, int64_t n_pad, int64_t n_valid);
