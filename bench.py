@@ -109,7 +109,7 @@ def pmc_traffic(args, sharded):
     if sharded or (args.n, args.d, args.layers, args.act, args.dtype) != (16384, 3072, 4, "relu", "f32"):
         return None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01e_pmc_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r01f_pmc_traffic.json")) as f:
             return json.load(f)["traffic_bytes_per_launch"]
     except Exception:
         return None
@@ -310,7 +310,7 @@ def main():
             "peak": peak, "unit": "TFLOP/s",
             "frac": (trail_fl / (trail_ms * 1e-3) / 1e12 / peak) if trail_ms > 0 else None,
             # HBM-side bytes per launch cannot be read without rocprofv3: taken from the committed PMC pass of this
-            # exact workload (profiles/r01e_pmc_traffic.json: FETCH_SIZE x2 + WRITE_SIZE, separate passes), else null
+            # exact workload (profiles/r01f_pmc_traffic.json: FETCH_SIZE x2 + WRITE_SIZE, separate passes), else null
             "traffic": pmc_traffic(args, sharded),
             "launches_per_step": per["trail"][1], "avg_launch_ms": trail_ms / max(per["trail"][1], 1),
             "flops_per_step": trail_fl,
