@@ -345,7 +345,13 @@ def test_rccl_communicator_in_a_process_that_also_holds_torch(torch_first):
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("act", ["relu", "erf"])
-@pytest.mark.parametrize("shape,layers", [((7, 5, 4, 3), 2), ((9, 8, 8, 1), 4), ((5, 1, 1, 6), 3), ((3, 32, 32, 3), 1)])
+@pytest.mark.parametrize("shape,layers", [((7, 5, 4, 3), 2), ((9, 8, 8, 1), 4), ((5, 1, 1, 6), 3), ((3, 32, 32, 3), 1),
+                                          # every pixels-per-lane form of the pair kernel, exact and ragged:
+                                          ((4, 16, 16, 2), 3),      # 256 px = 64 x 4, exact
+                                          ((3, 28, 28, 1), 2),      # 784 px: ragged 16-per-lane form (dummy-slot lanes)
+                                          ((3, 20, 20, 2), 3),      # 400 px: ragged, most of the last rounds empty
+                                          ((2, 40, 40, 1), 2),      # 1600 px: ragged 64-per-lane form
+                                          ((2, 64, 64, 1), 1)])     # 4096 px: the largest image, exact
 def test_cnn_kernel(dtype, act, shape, layers):
     """get_cnn_kernel (nt_kernels.py:34-45): symmetric, cross and odd image shapes vs the oracle."""
     from smnngp import nt_kernels
