@@ -97,6 +97,7 @@ struct PairArgs {
   int64_t n1, n2; int symmetric, mirror;
   ConvProg prog;
   T* out; int64_t ldo; int64_t npairs;
+  int tile_bn;   // > 0: XCD-tiled pair order (below), tiles of tile_bn x 32 image pairs; 0: plain strided order
 };
 
 constexpr int kMaxPix = 64;   // pixels per lane (H*W <= 4096)
@@ -117,9 +118,17 @@ constexpr int kMaxPix = 64;   // pixels per lane (H*W <= 4096)
 #ifndef SMN_CNN_OCC_F64
 #define SMN_CNN_OCC_F64 4   // workgroups per CU the f64 form is compiled for (128 VGPRs, 9 spilled doubles; 2 / 3: -6 %)
 #endif
+template <typename T>
+constexpr int pair_occ(int np, bool exact) {   // workgroups per CU a form is compiled for (and launched at)
+  return np > 16 ? 1 : np <= 4 ? 4 : !exact ? 2 : sizeof(T) == 8 ? SMN_CNN_OCC_F64 : SMN_CNN_OCC_F32;
+}
+// Pair order.  Every pair streams two images' inputs and factor tables (56 KB in f64 for 32x32x3, 4 layers); in the plain
+// order the waves in flight touch ~8k different images, far beyond the 4 MB L2 of an XCD, and the f64 kernel spent 75 % of
+// its wave cycles waiting on those loads (VALU busy 49 %, rocprofv3 PMC).  Tiled order: the grid is exactly the resident
+// set, workgroup b runs on XCD b % 8 (round-robin dispatch), and the workgroups of one XCD walk tiles of tile_bn x 32
+// pairs together -- one pair per wave per tile -- so an XCD's L2 holds the tile_bn + 32 images its waves are reading.
 template <typename T, int ACT, int NP, bool EXACT>
-__global__ void __launch_bounds__(256, NP > 16 ? 1 : NP <= 4 ? 4 : !EXACT ? 2 : sizeof(T) == 8 ? SMN_CNN_OCC_F64 : SMN_CNN_OCC_F32)
-conv_pair_kernel(PairArgs<T> a) {
+__global__ void __launch_bounds__(256, pair_occ<T>(NP, EXACT)) conv_pair_kernel(PairArgs<T> a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const ConvProg& p = a.prog;
   const int H = p.H, W = p.W, HW = H * W, PW = W + 2, PSZ = (H + 2) * PW;
@@ -136,18 +145,44 @@ conv_pair_kernel(PairArgs<T> a) {
   auto pix = [&](int i) { return EXACT ? lane + 64 * i : min(lane + 64 * i, HW - 1); };   // pixel a lane loads from
   const T w2_9 = (T)(p.w2 / 9.0), b2 = (T)p.b2;
   const T inv_c = (T)(1.0 / p.C);
-  const int64_t stride = (int64_t)gridDim.x * 4;
-  for (int64_t pr = (int64_t)blockIdx.x * 4 + wave; pr < a.npairs; pr += stride) {
+  // tiled order: XCD x walks the lower (or all) tiles with (tn + tm) % 8 == x, row by row -- dealt round-robin inside a
+  // tile row with the offset rotating from row to row, so every XCD gets the same share of the triangle
+  const bool tiled = a.tile_bn > 0;
+  const int xcd = (int)(blockIdx.x & 7);
+  const int tidx = (int)(blockIdx.x >> 3) * 4 + wave;   // this wave's pair inside every tile of its XCD
+  const int64_t tiles_m = (a.n2 + 31) / 32, tiles_n = tiled ? (a.n1 + a.tile_bn - 1) / a.tile_bn : 0;
+  auto row_tiles = [&](int64_t tn) -> int64_t {         // tiles of tile row tn that hold at least one wanted pair
+    if (!a.symmetric) return tiles_m;
+    const int64_t c = (tn * a.tile_bn + a.tile_bn - 1) / 32 + 1;
+    return c < tiles_m ? c : tiles_m;
+  };
+  int64_t tn = 0, tm = xcd - 8;
+  int64_t pr = (int64_t)blockIdx.x * 4 + wave - (int64_t)gridDim.x * 4;
+  for (;;) {
     int64_t n, m;
-    if (a.symmetric) {
-      int64_t r = (int64_t)((sqrt(8.0 * (double)pr + 1.0) - 1.0) * 0.5);
-      while ((r + 1) * (r + 2) / 2 <= pr) ++r;
-      while (r * (r + 1) / 2 > pr) --r;
-      n = r;
-      m = pr - r * (r + 1) / 2;
+    if (tiled) {
+      tm += 8;
+      while (tn < tiles_n && tm >= row_tiles(tn)) {
+        ++tn;
+        tm = (xcd - tn) & 7;
+      }
+      if (tn >= tiles_n) break;
+      n = tn * a.tile_bn + (tidx >> 5);
+      m = tm * 32 + (tidx & 31);
+      if (n >= a.n1 || m >= a.n2 || (a.symmetric && m > n)) continue;   // wave-uniform
     } else {
-      n = pr / a.n2;
-      m = pr % a.n2;
+      pr += (int64_t)gridDim.x * 4;
+      if (pr >= a.npairs) break;
+      if (a.symmetric) {
+        int64_t r = (int64_t)((sqrt(8.0 * (double)pr + 1.0) - 1.0) * 0.5);
+        while ((r + 1) * (r + 2) / 2 <= pr) ++r;
+        while (r * (r + 1) / 2 > pr) --r;
+        n = r;
+        m = pr - r * (r + 1) / 2;
+      } else {
+        n = pr / a.n2;
+        m = pr % a.n2;
+      }
     }
     // K0 map: channel loop outside, pixel loop inside, so the 2 NP loads of one channel are in flight together
     const T* xa = a.x1 + n * HW * p.C;
@@ -211,11 +246,23 @@ conv_pair_kernel(PairArgs<T> a) {
 }
 
 template <typename T, int ACT>
-int launch_pairs(smn_ctx* ctx, const PairArgs<T>& a, int64_t blocks, size_t lds, int64_t hw) {
+int launch_pairs(smn_ctx* ctx, const PairArgs<T>& a0, int64_t blocks, size_t lds, int64_t hw) {
+  PairArgs<T> a = a0;
 #define PAIR_CASE(NP)                                                                                              \
   if (hw <= 64 * NP) {                                                                                             \
     auto kern = (hw == 64 * NP) ? conv_pair_kernel<T, ACT, NP, true> : conv_pair_kernel<T, ACT, NP, false>;        \
     SMN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    /* tiled pair order once there are >= 64 tiles per XCD: the grid is exactly the resident set (a multiple of   \
+       64 workgroups, so a tile is a whole number of 32-pair rows); cnn_tiled: 0 never, 2 always (tests) */        \
+    int per_cu = 0;                                                                                                \
+    if (ctx->cnn_tiled > 0 &&                                                                                      \
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, lds) == hipSuccess && per_cu > 0) {       \
+      const int64_t g = (int64_t)ctx->num_cu * per_cu / 64 * 64;                                                   \
+      if (g >= 64 && (ctx->cnn_tiled == 2 || a.npairs >= 64 * 8 * (g / 8) * 4)) {                                 \
+        blocks = g;                                                                                                \
+        a.tile_bn = (int)(g / 64);                                                                                 \
+      }                                                                                                            \
+    }                                                                                                              \
     ProfScope ps(ctx, PROF_BUILD, ctx->stream);                                                                    \
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, ctx->stream, a);                              \
     return SMN_OK;                                                                                                 \
@@ -265,6 +312,7 @@ int cnn_t(smn_ctx* ctx, int act, int layers, double w, double b, double lw, cons
   a.npairs = sym ? n1 * (n1 + 1) / 2 : n1 * n2;
   int64_t blocks = (a.npairs + 3) / 4;
   if (blocks > 256 * 8) blocks = 256 * 8;   // persistent-ish: waves stride over the pair list
+  a.tile_bn = 0;
   SMN_TRY(act == SMN_ACT_RELU ? (launch_pairs<T, 0>(ctx, a, blocks, lds_p, HW)) : (launch_pairs<T, 1>(ctx, a, blocks, lds_p, HW)));
   SMN_CHECK_LAUNCH(ctx);
   return SMN_OK;

@@ -5,7 +5,7 @@ from smnngp import _lib as L
 ctx = L.Context(0)
 rng = np.random.default_rng(0)
 for dt in (np.float32, np.float64):
-    for n in (256, 1024):
+    for n in (256, 1024, 2048):
         x = ctx.to_device(rng.uniform(0, 1, (n, 32, 32, 3)).astype(dt))
         k = ctx.empty((n, n), dt)
         def run():

@@ -371,6 +371,45 @@ def test_cnn_kernel(dtype, act, shape, layers):
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_cnn_kernel_tiled_pair_order(L, dtype):
+    """Large pair counts take the XCD-tiled pair order (cnn.hip): symmetric (ragged last tiles, half-empty diagonal
+    tiles) and cross kernels against the oracle, and bit for bit against the plain order (SMN_CNN_TILED=0)."""
+    import os
+    rng = np.random.default_rng(3)
+    n1, n2, shape = 421, 333, (6, 6, 1)
+    x = rng.standard_normal((n1,) + shape).astype(dtype)
+    x2 = rng.standard_normal((n2,) + shape).astype(dtype)
+
+    def run(env):
+        old = os.environ.get("SMN_CNN_TILED")
+        if env is not None:
+            os.environ["SMN_CNN_TILED"] = env
+        try:
+            c = L.Context(0)
+        finally:
+            if env is not None:
+                if old is None:
+                    del os.environ["SMN_CNN_TILED"]
+                else:
+                    os.environ["SMN_CNN_TILED"] = old
+        xd, x2d = c.to_device(x), c.to_device(x2)
+        ks, kc = c.empty((n1, n1), dtype), c.empty((n1, n2), dtype)
+        code = L.dtype_code(dtype)
+        c.call("smn_kernel_cnn", code, L.ACT["relu"], 2, 1.3, 0.2, 0.9, xd.ptr, n1, None, 0, 6, 6, 1, L.FILL_FULL, ks.ptr, n1)
+        c.call("smn_kernel_cnn", code, L.ACT["relu"], 2, 1.3, 0.2, 0.9, xd.ptr, n1, x2d.ptr, n2, 6, 6, 1, L.FILL_FULL, kc.ptr, n2)
+        return ks.numpy(), kc.numpy()
+
+    ks, kc = run("2")      # tiled at any size
+    ks0, kc0 = run("0")
+    assert np.array_equal(ks, ks0) and np.array_equal(kc, kc0)
+    assert np.array_equal(ks, ks.T)
+    ref = O.cnn_kernel(x.astype(np.float64), None, 2, "relu", 1.3, 0.2, 0.9)
+    refc = O.cnn_kernel(x.astype(np.float64), x2.astype(np.float64), 2, "relu", 1.3, 0.2, 0.9)
+    assert relerr(ks, ref) < RTOL[dtype] and relerr(kc, refc) < RTOL[dtype]
+    assert np.abs(ks - ref).max() < RTOL[dtype] * np.abs(ref).max()           # no pair skipped or misplaced
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("act", ["relu", "erf"])
 @pytest.mark.parametrize("shape,block", [((6, 8, 8, 3), 1), ((5, 16, 8, 2), 2), ((3, 32, 32, 3), 1), ((4, 8, 24, 1), 3)])
 def test_conv_resnet_kernel(dtype, act, shape, block):
