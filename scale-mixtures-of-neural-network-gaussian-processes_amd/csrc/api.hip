@@ -210,6 +210,7 @@ extern "C" int smn_ctx_create(int device_id, smn_ctx** out) {
   if (const char* e = getenv("SMN_PERSISTENT")) c->persistent_trail = e[0] != '0';
   if (const char* e = getenv("SMN_REC_SYM")) c->rec_sym = e[0] != '0';
   if (const char* e = getenv("SMN_CNN_TILED")) c->cnn_tiled = atoi(e);
+  if (const char* e = getenv("SMN_CNN_FAST32")) c->cnn_fast32 = atoi(e);
   if (const char* e = getenv("SMN_PERSIST_MAXK")) c->persist_max_k = atoi(e);
   if (const char* e = getenv("SMN_HALF_TILES")) c->half_tile_max = atoi(e);
   if (const char* e = getenv("SMN_QUARTER_TILES")) c->quarter_tile_max = atoi(e);

@@ -118,6 +118,59 @@ constexpr int kMaxPix = 64;   // pixels per lane (H*W <= 4096)
 #ifndef SMN_CNN_OCC_F64
 #define SMN_CNN_OCC_F64 4   // workgroups per CU the f64 form is compiled for (128 VGPRs, 9 spilled doubles; 2 / 3: -6 %)
 #endif
+// The pair list of one wave: plain strided order, or the XCD-tiled order described below.  next() is wave-uniform.
+template <typename T>
+struct PairWalk {
+  const PairArgs<T>& a;
+  bool tiled; int xcd, tidx; int64_t tiles_m, tiles_n, tn, tm, pr, step;
+  __device__ __forceinline__ PairWalk(const PairArgs<T>& a_, int wave) : a(a_) {
+    tiled = a.tile_bn > 0;
+    xcd = (int)(blockIdx.x & 7);
+    tidx = (int)(blockIdx.x >> 3) * 4 + wave;   // this wave's pair inside every tile of its XCD
+    tiles_m = (a.n2 + 31) / 32;
+    tiles_n = tiled ? (a.n1 + a.tile_bn - 1) / a.tile_bn : 0;
+    tn = 0;
+    tm = xcd - 8;
+    step = (int64_t)gridDim.x * 4;
+    pr = (int64_t)blockIdx.x * 4 + wave - step;
+  }
+  __device__ __forceinline__ int64_t row_tiles(int64_t r) const {   // tiles of tile row r that hold a wanted pair
+    if (!a.symmetric) return tiles_m;
+    const int64_t c = (r * a.tile_bn + a.tile_bn - 1) / 32 + 1;
+    return c < tiles_m ? c : tiles_m;
+  }
+  __device__ __forceinline__ bool next(int64_t& n, int64_t& m) {
+    if (tiled) {
+      // XCD x walks the lower (or all) tiles with (tn + tm) % 8 == x, row by row: dealt round-robin inside a tile row
+      // with the offset rotating from row to row, so every XCD gets the same share of the triangle
+      for (;;) {
+        tm += 8;
+        while (tn < tiles_n && tm >= row_tiles(tn)) {
+          ++tn;
+          tm = (xcd - tn) & 7;
+        }
+        if (tn >= tiles_n) return false;
+        n = tn * a.tile_bn + (tidx >> 5);
+        m = tm * 32 + (tidx & 31);
+        if (n < a.n1 && m < a.n2 && !(a.symmetric && m > n)) return true;
+      }
+    }
+    pr += step;
+    if (pr >= a.npairs) return false;
+    if (a.symmetric) {
+      int64_t r = (int64_t)((sqrt(8.0 * (double)pr + 1.0) - 1.0) * 0.5);
+      while ((r + 1) * (r + 2) / 2 <= pr) ++r;
+      while (r * (r + 1) / 2 > pr) --r;
+      n = r;
+      m = pr - r * (r + 1) / 2;
+    } else {
+      n = pr / a.n2;
+      m = pr % a.n2;
+    }
+    return true;
+  }
+};
+
 template <typename T>
 constexpr int pair_occ(int np, bool exact) {   // workgroups per CU a form is compiled for (and launched at)
   return np > 16 ? 1 : np <= 4 ? 4 : !exact ? 2 : sizeof(T) == 8 ? SMN_CNN_OCC_F64 : SMN_CNN_OCC_F32;
@@ -136,54 +189,24 @@ __global__ void __launch_bounds__(256, pair_occ<T>(NP, EXACT)) conv_pair_kernel(
   const int MSZ = PSZ + 2 * PW + 3;                     // map + the dummy slot's neighbourhood
   T* map = reinterpret_cast<T*>(smem) + (size_t)wave * MSZ;
   for (int i = lane; i < MSZ; i += 64) map[i] = T(0);   // halo stays zero for the whole kernel
-  int off[NP];                                          // centre of pixel lane + 64 i in the padded map
+  // centre of pixel lane + 64 i in the padded map.  EXACT forms (W divides 64 as well): pixel i sits 64 / W rows below
+  // pixel i - 1, so the offsets are off0 + i * rstep and no per-pixel table is kept in registers.
+  int off_tab[EXACT ? 1 : NP];
+  const int off0 = (lane / W + 1) * PW + lane % W + 1, rstep = (64 / W) * PW;
+  if (!EXACT) {
 #pragma unroll
-  for (int i = 0; i < NP; ++i) {
-    const int px = lane + 64 * i;
-    off[i] = (EXACT || px < HW) ? (px / W + 1) * PW + px % W + 1 : PSZ + PW + 1;
+    for (int i = 0; i < NP; ++i) {
+      const int px = lane + 64 * i;
+      off_tab[i] = px < HW ? (px / W + 1) * PW + px % W + 1 : PSZ + PW + 1;
+    }
   }
+  auto off = [&](int i) { return EXACT ? off0 + i * rstep : off_tab[EXACT ? 0 : i]; };
   auto pix = [&](int i) { return EXACT ? lane + 64 * i : min(lane + 64 * i, HW - 1); };   // pixel a lane loads from
   const T w2_9 = (T)(p.w2 / 9.0), b2 = (T)p.b2;
   const T inv_c = (T)(1.0 / p.C);
-  // tiled order: XCD x walks the lower (or all) tiles with (tn + tm) % 8 == x, row by row -- dealt round-robin inside a
-  // tile row with the offset rotating from row to row, so every XCD gets the same share of the triangle
-  const bool tiled = a.tile_bn > 0;
-  const int xcd = (int)(blockIdx.x & 7);
-  const int tidx = (int)(blockIdx.x >> 3) * 4 + wave;   // this wave's pair inside every tile of its XCD
-  const int64_t tiles_m = (a.n2 + 31) / 32, tiles_n = tiled ? (a.n1 + a.tile_bn - 1) / a.tile_bn : 0;
-  auto row_tiles = [&](int64_t tn) -> int64_t {         // tiles of tile row tn that hold at least one wanted pair
-    if (!a.symmetric) return tiles_m;
-    const int64_t c = (tn * a.tile_bn + a.tile_bn - 1) / 32 + 1;
-    return c < tiles_m ? c : tiles_m;
-  };
-  int64_t tn = 0, tm = xcd - 8;
-  int64_t pr = (int64_t)blockIdx.x * 4 + wave - (int64_t)gridDim.x * 4;
-  for (;;) {
-    int64_t n, m;
-    if (tiled) {
-      tm += 8;
-      while (tn < tiles_n && tm >= row_tiles(tn)) {
-        ++tn;
-        tm = (xcd - tn) & 7;
-      }
-      if (tn >= tiles_n) break;
-      n = tn * a.tile_bn + (tidx >> 5);
-      m = tm * 32 + (tidx & 31);
-      if (n >= a.n1 || m >= a.n2 || (a.symmetric && m > n)) continue;   // wave-uniform
-    } else {
-      pr += (int64_t)gridDim.x * 4;
-      if (pr >= a.npairs) break;
-      if (a.symmetric) {
-        int64_t r = (int64_t)((sqrt(8.0 * (double)pr + 1.0) - 1.0) * 0.5);
-        while ((r + 1) * (r + 2) / 2 <= pr) ++r;
-        while (r * (r + 1) / 2 > pr) --r;
-        n = r;
-        m = pr - r * (r + 1) / 2;
-      } else {
-        n = pr / a.n2;
-        m = pr % a.n2;
-      }
-    }
+  PairWalk<T> walk(a, wave);
+  int64_t n, m;
+  while (walk.next(n, m)) {
     // K0 map: channel loop outside, pixel loop inside, so the 2 NP loads of one channel are in flight together
     const T* xa = a.x1 + n * HW * p.C;
     const T* xb = a.x2 + m * HW * p.C;
@@ -213,13 +236,13 @@ __global__ void __launch_bounds__(256, pair_occ<T>(NP, EXACT)) conv_pair_kernel(
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
-      for (int i = 0; i < NP; ++i) map[off[i]] = val[i];
+      for (int i = 0; i < NP; ++i) map[off(i)] = val[i];
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int i = 0; i < NP; ++i) {
         const T rr = r1[pix(i)] * r2[pix(i)];
-        const T* c = map + off[i];
+        const T* c = map + off(i);
         const T bs = ((c[-PW - 1] + c[-PW]) + (c[-PW + 1] + c[-1])) + ((c[0] + c[1]) + (c[PW - 1] + c[PW])) + c[PW + 1];
         const T kt = fma(w2_9, bs, b2);
         if (ACT == 0) {
@@ -245,27 +268,152 @@ __global__ void __launch_bounds__(256, pair_occ<T>(NP, EXACT)) conv_pair_kernel(
   }
 }
 
+// ---------------------------------------------------------------- 32 x 32 images (CIFAR: BASELINE.json's C3)
+// The 3x3 box sum without LDS.  Lane l holds column l & 31 of rows 2i + (l >> 5), i = 0..15, so
+//   horizontal:  the neighbours of a pixel are the same register of lanes l -+ 1 (DPP wave_shr / wave_shl; the image
+//                border columns are masked by a per-lane 0/1 factor folded into the add),
+//   vertical:    v_permlane32_swap turns the register of row pair i into E_i = row 2i and O_i = row 2i+1, each in ALL
+//                lanes; a lower lane (row 2i) adds O_{i-1} + E_i + O_i, an upper lane (row 2i+1) E_i + O_i + E_{i+1}.
+// No map, no halo, no LDS instruction in the layer loop: what is left to wait for are the factor-table loads.
+template <typename T>
+__device__ __forceinline__ T dpp_lane(T v, bool left);
+template <>
+__device__ __forceinline__ float dpp_lane<float>(float v, bool left) {
+  const int x = __float_as_int(v);
+  return __int_as_float(left ? __builtin_amdgcn_update_dpp(0, x, 0x138, 0xf, 0xf, false)     // wave_shr:1: lane l-1
+                             : __builtin_amdgcn_update_dpp(0, x, 0x130, 0xf, 0xf, false));   // wave_shl:1: lane l+1
+}
+template <>
+__device__ __forceinline__ double dpp_lane<double>(double v, bool left) {
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  if (left)
+    return __hiloint2double(__builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, false),
+                            __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xf, 0xf, false));
+  return __hiloint2double(__builtin_amdgcn_update_dpp(0, hi, 0x130, 0xf, 0xf, false),
+                          __builtin_amdgcn_update_dpp(0, lo, 0x130, 0xf, 0xf, false));
+}
+// e = the lower half-wave's values in all lanes, o = the upper half-wave's (scratch/dpp_probe: permlane32_swap(x, x))
+__device__ __forceinline__ void rows32(float h, float& e, float& o) {
+  const int x = __float_as_int(h);
+  const auto p = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+  e = __int_as_float((int)p[0]);
+  o = __int_as_float((int)p[1]);
+}
+__device__ __forceinline__ void rows32(double h, double& e, double& o) {
+  const int lo = __double2loint(h), hi = __double2hiint(h);
+  const auto pl = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  const auto ph = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  e = __hiloint2double((int)ph[0], (int)pl[0]);
+  o = __hiloint2double((int)ph[1], (int)pl[1]);
+}
+
+#ifndef SMN_CNN32_OCC
+#define SMN_CNN32_OCC 2
+#endif
 template <typename T, int ACT>
-int launch_pairs(smn_ctx* ctx, const PairArgs<T>& a0, int64_t blocks, size_t lds, int64_t hw) {
-  PairArgs<T> a = a0;
-#define PAIR_CASE(NP)                                                                                              \
-  if (hw <= 64 * NP) {                                                                                             \
-    auto kern = (hw == 64 * NP) ? conv_pair_kernel<T, ACT, NP, true> : conv_pair_kernel<T, ACT, NP, false>;        \
-    SMN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-    /* tiled pair order once there are >= 64 tiles per XCD: the grid is exactly the resident set (a multiple of   \
-       64 workgroups, so a tile is a whole number of 32-pair rows); cnn_tiled: 0 never, 2 always (tests) */        \
-    int per_cu = 0;                                                                                                \
-    if (ctx->cnn_tiled > 0 &&                                                                                      \
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, lds) == hipSuccess && per_cu > 0) {       \
-      const int64_t g = (int64_t)ctx->num_cu * per_cu / 64 * 64;                                                   \
-      if (g >= 64 && (ctx->cnn_tiled == 2 || a.npairs >= 64 * 8 * (g / 8) * 4)) {                                 \
-        blocks = g;                                                                                                \
-        a.tile_bn = (int)(g / 64);                                                                                 \
-      }                                                                                                            \
-    }                                                                                                              \
-    ProfScope ps(ctx, PROF_BUILD, ctx->stream);                                                                    \
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, ctx->stream, a);                              \
-    return SMN_OK;                                                                                                 \
+__global__ void __launch_bounds__(256, SMN_CNN32_OCC) conv_pair32_kernel(PairArgs<T> a) {
+  constexpr int NP = 16, HW = 1024;
+  const ConvProg& p = a.prog;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = lane & 31;
+  const bool upper = lane >= 32;
+  const T ml = col > 0 ? T(1) : T(0), mr = col < 31 ? T(1) : T(0);
+  const T w2_9 = (T)(p.w2 / 9.0), b2 = (T)p.b2;
+  const T inv_c = (T)(1.0 / p.C);
+  PairWalk<T> walk(a, wave);
+  int64_t n, m;
+  while (walk.next(n, m)) {
+    const T* xa = a.x1 + n * HW * p.C;
+    const T* xb = a.x2 + m * HW * p.C;
+    T val[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) val[i] = T(0);
+    for (int c = 0; c < p.C; ++c) {
+#pragma unroll
+      for (int i0 = 0; i0 < NP; i0 += 4) {   // 8 loads in flight per batch
+        T va[4], vb[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          va[j] = xa[(lane + 64 * (i0 + j)) * p.C + c];
+          vb[j] = xb[(lane + 64 * (i0 + j)) * p.C + c];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) val[i0 + j] = fma(va[j], vb[j], val[i0 + j]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NP; ++i) val[i] *= inv_c;
+    for (int l = 0; l < p.layers; ++l) {
+      const T* r1 = a.R1 + (n * p.layers + l) * HW + lane;
+      const T* r2 = a.R2 + (m * p.layers + l) * HW + lane;
+      T e[NP], o[NP];
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        const T h = fma(ml, dpp_lane<T>(val[i], true), fma(mr, dpp_lane<T>(val[i], false), val[i]));
+        rows32(h, e[i], o[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        const T above = i > 0 ? o[i - 1] : T(0);        // row 2i - 1, for the lower lanes
+        const T below = i + 1 < NP ? e[i + 1] : T(0);   // row 2i + 2, for the upper lanes
+        const T bs = (e[i] + o[i]) + (upper ? below : above);
+        const T rr = r1[64 * i] * r2[64 * i];
+        const T kt = fma(w2_9, bs, b2);
+        if (ACT == 0) {
+          const T ss = rr > T(0) ? T(1.0 / (2.0 * nngp::kPi)) * rcp_any<T>(rr) : T(0);
+          val[i] = nngp::relu_map<T, false>(kt, rr, ss).k;
+        } else {
+          val[i] = nngp::erf_map<T, false>(kt, rr, T(0)).k;
+        }
+      }
+    }
+    T s = T(0);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) s += val[i];
+#pragma unroll
+    for (int o2 = 32; o2 > 0; o2 >>= 1) s += __shfl_xor(s, o2);
+    if (lane == 0) {
+      T v = (T)p.lw2 * s / (T)HW;
+      if (a.symmetric && n == m) v = a.diag[n];
+      a.out[n * a.ldo + m] = v;
+      if (a.symmetric && a.mirror && n != m) a.out[m * a.ldo + n] = v;
+    }
+  }
+}
+
+// Launch one form of the pair kernel.  Tiled pair order once there are >= 64 tiles per XCD: the grid is then exactly the
+// resident set (occupancy API; a multiple of 64 workgroups, so a tile is a whole number of 32-pair rows).
+// cnn_tiled: 0 never, 1 by size, 2 always (tests).
+template <typename T, typename K>
+int launch_pair_form(smn_ctx* ctx, K kern, PairArgs<T> a, int64_t blocks, size_t lds) {
+  if (lds > 0)
+    SMN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  int per_cu = 0;
+  if (ctx->cnn_tiled > 0 && hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, lds) == hipSuccess &&
+      per_cu > 0) {
+    const int64_t g = (int64_t)ctx->num_cu * per_cu / 64 * 64;
+    if (g >= 64 && (ctx->cnn_tiled == 2 || a.npairs >= 64 * 8 * (g / 8) * 4)) {
+      blocks = g;
+      a.tile_bn = (int)(g / 64);
+    }
+  }
+  ProfScope ps(ctx, PROF_BUILD, ctx->stream);
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, ctx->stream, a);
+  return SMN_OK;
+}
+
+template <typename T, int ACT>
+int launch_pairs(smn_ctx* ctx, const PairArgs<T>& a, int64_t blocks, size_t lds, int64_t hw) {
+  // register-only stencil, no LDS: fp64 by default (+2 ... +11 % with growing N; the fp32 LDS-map kernel is VALU-bound at
+  // 72 % busy and 5 % FASTER than its register form: profiles/r01f_cnn_fast32_ab.txt); cnn_fast32 = 2 forces it for both
+  if (a.prog.H == 32 && a.prog.W == 32 && (ctx->cnn_fast32 == 2 || (ctx->cnn_fast32 == 1 && sizeof(T) == 8)))
+    return launch_pair_form<T>(ctx, conv_pair32_kernel<T, ACT>, a, blocks, 0);
+#define PAIR_CASE(NP)                                                                                         \
+  if (hw <= 64 * NP) {                                                                                        \
+    if (hw == 64 * NP && 64 % a.prog.W == 0)                                                                  \
+      return launch_pair_form<T>(ctx, conv_pair_kernel<T, ACT, NP, true>, a, blocks, lds);                    \
+    return launch_pair_form<T>(ctx, conv_pair_kernel<T, ACT, NP, false>, a, blocks, lds);                     \
   }
   PAIR_CASE(4)
   PAIR_CASE(16)

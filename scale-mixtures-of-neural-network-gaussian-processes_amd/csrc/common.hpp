@@ -52,6 +52,7 @@ struct smn_ctx {
   int quarter_tile_max = 256;        // ... and with at most this many, 64x64 tiles (env SMN_QUARTER_TILES)
   int half_tile_max = 384;           // trailing launches with at most this many 128x128 tiles use 64-row tiles (env SMN_HALF_TILES)
   int persist_max_k = 512;           // largest K the persistent trailing kernel takes (env SMN_PERSIST_MAXK)
+  int cnn_fast32 = 1;                // conv-NNGP: register-only 3x3 stencil for 32x32 images (env SMN_CNN_FAST32: 0 never, 1 fp64 only, 2 both)
   int cnn_tiled = 1;                 // conv-NNGP pair kernel: XCD-tiled pair order for large problems (env SMN_CNN_TILED: 0 never, 2 always)
   bool rec_sym = true;               // stand-alone recursion: lower-tile + mirror kernel when symmetric (env SMN_REC_SYM=0)
   bool persistent_trail = true;      // persistent trailing-update kernel (env SMN_PERSISTENT=0 disables)

@@ -347,6 +347,7 @@ def test_rccl_communicator_in_a_process_that_also_holds_torch(torch_first):
 @pytest.mark.parametrize("act", ["relu", "erf"])
 @pytest.mark.parametrize("shape,layers", [((7, 5, 4, 3), 2), ((9, 8, 8, 1), 4), ((5, 1, 1, 6), 3), ((3, 32, 32, 3), 1),
                                           # every pixels-per-lane form of the pair kernel, exact and ragged:
+                                          ((4, 32, 32, 2), 4),      # 32 x 32: the register-only stencil, all 4 layers
                                           ((4, 16, 16, 2), 3),      # 256 px = 64 x 4, exact
                                           ((3, 28, 28, 1), 2),      # 784 px: ragged 16-per-lane form (dummy-slot lanes)
                                           ((3, 20, 20, 2), 3),      # 400 px: ragged, most of the last rounds empty
@@ -368,6 +369,45 @@ def test_cnn_kernel(dtype, act, shape, layers):
     assert kc.shape == (shape[0], 4) and relerr(kc, refc) < RTOL[dtype]
     with pytest.raises(NotImplementedError):
         kfn(x, None, get="ntk")
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("act", ["relu", "erf"])
+def test_cnn_kernel_32x32_stencil_in_registers_matches_the_lds_map_kernel(L, dtype, act):
+    """32 x 32 images take conv_pair32_kernel (3x3 box sums by DPP lane shifts + v_permlane32_swap, no LDS); the generic
+    LDS-map kernel (SMN_CNN_FAST32=0) must give the same kernel: same sums in a different association order, so to a
+    few ulp, and both against the oracle.  Images with structure at the borders (a constant image makes every border
+    and corner pixel a distinct case)."""
+    import os
+    rng = np.random.default_rng(11)
+    n = 6
+    x = rng.standard_normal((n, 32, 32, 3))
+    x[0] = 1.0                      # constant image
+    x[1, 0, :, :] = 5.0             # loud top row
+    x[2, :, 31, :] = -4.0           # loud right column
+    x[3, 31, 0, :] = 7.0            # loud corner
+    x = x.astype(dtype)
+
+    def run(env):
+        old = os.environ.get("SMN_CNN_FAST32")
+        os.environ["SMN_CNN_FAST32"] = env
+        try:
+            c = L.Context(0)
+        finally:
+            if old is None:
+                del os.environ["SMN_CNN_FAST32"]
+            else:
+                os.environ["SMN_CNN_FAST32"] = old
+        xd = c.to_device(x)
+        k = c.empty((n, n), dtype)
+        c.call("smn_kernel_cnn", L.dtype_code(dtype), L.ACT[act], 4, 1.2, 0.3, 0.9, xd.ptr, n, None, 0, 32, 32, 3, L.FILL_FULL, k.ptr, n)
+        return k.numpy()
+
+    fast, slow = run("2"), run("0")      # 2: the register form in both precisions
+    ref = O.cnn_kernel(x.astype(np.float64), None, 4, act, 1.2, 0.3, 0.9)
+    tol = 1e-12 if dtype == np.float64 else 2e-5
+    assert np.abs(fast - slow).max() < tol * np.abs(ref).max()
+    assert relerr(fast, ref) < RTOL[dtype] and relerr(slow, ref) < RTOL[dtype]
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
