@@ -112,6 +112,10 @@ constexpr int kMaxPix = 64;   // pixels per lane (H*W <= 4096)
 // Lanes whose pixel index runs past H*W are not branched around: they load from a clamped (valid) pixel, publish to
 // a dummy slot behind the map whose 3x3 neighbourhood is also behind the map, and are dropped from the final sum
 // (EXACT: H*W == 64*NP, there are none).
+#ifndef SMN_CNN_K0_BATCH
+#define SMN_CNN_K0_BATCH 16   // pixels whose K0 channel loads are issued together: the phase is pure load latency
+#endif                        // (4 -> 16: fp64 +12 %, fp32 +5 %, profiles/r01f_cnn_k0_batch_ab.txt)
+constexpr int KB0 = SMN_CNN_K0_BATCH;
 #ifndef SMN_CNN_OCC_F32
 #define SMN_CNN_OCC_F32 2   // f32 wants the registers (ILP over its pixels) more than the waves: 4 spills and loses 27 %
 #endif
@@ -204,6 +208,8 @@ __global__ void __launch_bounds__(256, pair_occ<T>(NP, EXACT)) conv_pair_kernel(
   auto pix = [&](int i) { return EXACT ? lane + 64 * i : min(lane + 64 * i, HW - 1); };   // pixel a lane loads from
   const T w2_9 = (T)(p.w2 / 9.0), b2 = (T)p.b2;
   const T inv_c = (T)(1.0 / p.C);
+  // (the fp64 16-pixel exact form lives on 128 VGPRs: a batch of 16 spills there and costs 20 %)
+  constexpr int KB = (sizeof(T) == 8 && EXACT && NP == 16) ? 4 : (KB0 < NP ? KB0 : NP);
   PairWalk<T> walk(a, wave);
   int64_t n, m;
   while (walk.next(n, m)) {
@@ -215,15 +221,15 @@ __global__ void __launch_bounds__(256, pair_occ<T>(NP, EXACT)) conv_pair_kernel(
     for (int i = 0; i < NP; ++i) val[i] = T(0);
     for (int c = 0; c < p.C; ++c) {
 #pragma unroll
-      for (int i0 = 0; i0 < NP; i0 += 4) {   // 8 loads in flight per batch
-        T va[4], vb[4];
+      for (int i0 = 0; i0 < NP; i0 += KB) {   // 2 KB loads in flight per batch
+        T va[KB], vb[KB];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < KB; ++j) {
           va[j] = xa[pix(i0 + j) * p.C + c];
           vb[j] = xb[pix(i0 + j) * p.C + c];
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) val[i0 + j] = fma(va[j], vb[j], val[i0 + j]);
+        for (int j = 0; j < KB; ++j) val[i0 + j] = fma(va[j], vb[j], val[i0 + j]);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -312,7 +318,7 @@ __device__ __forceinline__ void rows32(double h, double& e, double& o) {
 #endif
 template <typename T, int ACT>
 __global__ void __launch_bounds__(256, SMN_CNN32_OCC) conv_pair32_kernel(PairArgs<T> a) {
-  constexpr int NP = 16, HW = 1024;
+  constexpr int NP = 16, HW = 1024, KB = KB0 < NP ? KB0 : NP;
   const ConvProg& p = a.prog;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int col = lane & 31;
@@ -330,15 +336,15 @@ __global__ void __launch_bounds__(256, SMN_CNN32_OCC) conv_pair32_kernel(PairArg
     for (int i = 0; i < NP; ++i) val[i] = T(0);
     for (int c = 0; c < p.C; ++c) {
 #pragma unroll
-      for (int i0 = 0; i0 < NP; i0 += 4) {   // 8 loads in flight per batch
-        T va[4], vb[4];
+      for (int i0 = 0; i0 < NP; i0 += KB) {   // 2 KB loads in flight per batch
+        T va[KB], vb[KB];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < KB; ++j) {
           va[j] = xa[(lane + 64 * (i0 + j)) * p.C + c];
           vb[j] = xb[(lane + 64 * (i0 + j)) * p.C + c];
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) val[i0 + j] = fma(va[j], vb[j], val[i0 + j]);
+        for (int j = 0; j < KB; ++j) val[i0 + j] = fma(va[j], vb[j], val[i0 + j]);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -358,7 +364,7 @@ __global__ void __launch_bounds__(256, SMN_CNN32_OCC) conv_pair32_kernel(PairArg
         const T above = i > 0 ? o[i - 1] : T(0);        // row 2i - 1, for the lower lanes
         const T below = i + 1 < NP ? e[i + 1] : T(0);   // row 2i + 2, for the upper lanes
         const T bs = (e[i] + o[i]) + (upper ? below : above);
-        const T rr = r1[64 * i] * r2[64 * i];
+        const T rr = r1[64 * i] * r2[64 * i];   // (all 32 loads of the layer issued up front: 5 % slower, registers)
         const T kt = fma(w2_9, bs, b2);
         if (ACT == 0) {
           const T ss = rr > T(0) ? T(1.0 / (2.0 * nngp::kPi)) * rcp_any<T>(rr) : T(0);
