@@ -212,10 +212,26 @@ __global__ void __launch_bounds__(256) resnet_pair_kernel(RPairArgs<T> a) {
     int h = p.H, w = p.W, cur = 0, skip = -1, toff = 0;
     const T* xa = a.x1 + n * h * w * p.C;
     const T* xb = a.x2 + m * h * w * p.C;
-    for (int px = lane; px < h * w; px += 64) {
-      T s = T(0);
-      for (int c = 0; c < p.C; ++c) s = fma(xa[px * p.C + c], xb[px * p.C + c], s);
-      ms.b(0)[(px / w + 1) * PW + px % w + 1] = s * inv_c;
+    // channel loop outside, NB pixels inside: 2 NB loads in flight per channel (one dependent L2 round trip per pixel
+    // and channel made this phase pure latency: cnn.hip, profiles/r01f_notes.md).  fp32: +14 % on the whole kernel;
+    // fp64 lives at its register limit and loses 3 % with a batch of 8, so it keeps one pixel at a time.
+    constexpr int NB = sizeof(T) == 8 ? 1 : 8;
+    for (int px0 = lane; px0 < h * w; px0 += 64 * NB) {
+      T s[NB];
+#pragma unroll
+      for (int j = 0; j < NB; ++j) s[j] = T(0);
+      for (int c = 0; c < p.C; ++c) {
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+          const int pc = min(px0 + 64 * j, h * w - 1);
+          s[j] = fma(xa[pc * p.C + c], xb[pc * p.C + c], s[j]);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        const int px = px0 + 64 * j;
+        if (px < h * w) ms.b(0)[(px / w + 1) * PW + px % w + 1] = s[j] * inv_c;
+      }
     }
     ms.zero_ring(ms.b(0), h, w);
     ms.sync();
