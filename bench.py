@@ -376,6 +376,9 @@ def main():
                        "parallelism": "single GPU" if not sharded else "paired lower-block row shards x%d + one RCCL all-gather + replicated Cholesky" % world},
             "phases_ms": {k: round(v[0], 4) for k, v in per.items()},
             "phases_ms_source": "trail: hipEvents in the timed region; others: separate untimed pass with events on every launch",
+            # the north-star's "kernel-build speed-up at N GPUs" reads off these two (rank 0; every rank builds the same
+            # number of tiles): the fused Gram + recursion launch of this rank's shard, and all-gather + scatter
+            "kernel_build_ms": round(per["build"][0], 4), "exchange_ms": round(per["misc"][0], 4) if sharded else 0.0,
             "result": {"logpdf": lp.value, "logdet": logdet.value, "info": info.value},
             "roofline": roof,
         }
