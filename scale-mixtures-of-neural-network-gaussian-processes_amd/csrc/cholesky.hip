@@ -459,7 +459,8 @@ __global__ void __launch_bounds__(256, BN == 64 ? 4 : (BM == 64 ? (sizeof(T) == 
         const int64_t gc = col0 + wc * Tile::WN + n * M::TN + M::acc_col(lane);
         t.acc[m][n][i] = -u.a[gr * u.lda + gc];
       }
-  t.mainloop(u.a + row0 * u.lda + u.k0, u.lda, u.a + col0 * u.lda + u.k0, u.lda, u.K, smem);
+  // trailing updates (TAG 1) run K = 256 ... 1024: the pipelined K loop; strips (K = 128) the plain one
+  t.template mainloop<TAG == 1 ? 1 : 0>(u.a + row0 * u.lda + u.k0, u.lda, u.a + col0 * u.lda + u.k0, u.lda, u.K, smem);
 #pragma unroll
   for (int m = 0; m < Tile::MT; ++m)
 #pragma unroll

@@ -122,6 +122,36 @@ struct TileNT {
   // acc += A[0:BM, 0:K] * B[0:BN, 0:K]^T.  A/B point at the first row of the block; K % BK == 0,
   // lda/ldb % VEC == 0 and 16-byte aligned bases (the callers pad).  Ends with a barrier, so the
   // caller may reuse smem right away.
+  //
+  // Schedule of one K-step (KG fragment groups; double-buffered LDS stages, double-buffered fragments), written so that
+  // the MFMA stream of a wave never waits on the LDS (rocprofv3 PMC on the first version: MFMA issue slots busy 76-79 %,
+  // the rest per-K-step bubbles: fragment reads issued right in front of the MFMAs that need them, the staging writes
+  // and the first reads of the next step all behind the last MFMA):
+  //   group g          fragments of g+1 are read BEFORE the MFMAs of g (a whole group, 1k cycles, ahead of their use);
+  //   group WG         the next stage's ds_writes are spread between this group's MFMAs (their global loads were issued
+  //                    a K-step earlier);
+  //   group KG-1       the barrier sits IN FRONT of the last group's MFMAs: every wave has written the next stage and has
+  //                    issued all its reads of this one, the last group's fragments are already in registers, so the
+  //                    MFMAs start at once and the first fragments of the NEXT step + the global loads of the step after
+  //                    it ride under them.
+  // Same arithmetic in the same order as the plain loop (SMN_PIPE=0 keeps that one for A/B): identical bits.
+#ifndef SMN_PIPE
+#define SMN_PIPE 1
+#endif
+  __device__ __forceinline__ void frag_load(const char* stage, int g, int lane, int wr, int wc, vec_t (&a)[MT], vec_t (&b)[NT]) {
+    const char* sa = stage + (wr * WM) * ROWB;
+    const char* sb = stage + A_BYTES + (wc * WN) * ROWB;
+    const int fr = M::frag_row(lane);
+    const int off = fr * ROWB + ((M::frag_chunk(lane, g) ^ ((fr >> 1) & 7)) << 4);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) a[m] = *reinterpret_cast<const vec_t*>(sa + m * M::TM * ROWB + off);
+#pragma unroll
+    for (int n = 0; n < NT; ++n) b[n] = *reinterpret_cast<const vec_t*>(sb + n * M::TN * ROWB + off);
+  }
+
+  // MODE 1: pipelined loop only, 0: plain loop only, 2: chosen at run time (pipelined from 8 K-steps on).  Kernels that
+  // know their K range pick 0 or 1: one loop in the kernel instead of two keeps the f32 128x128 tile off the register limit.
+  template <int MODE = 2>
   __device__ __forceinline__ void mainloop(const T* __restrict__ A, int64_t lda,
                                            const T* __restrict__ B, int64_t ldb, int K, char* smem) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -132,28 +162,85 @@ struct TileNT {
     const T* gb = B + (int64_t)lrow * ldb + lchunk * M::VEC;
     vec_t ra[PA], rb[PB];
     const int nk = K / M::BK;
+    auto gload = [&](int kt) {
+      const int ko = kt * M::BK;
+#pragma unroll
+      for (int p = 0; p < PA; ++p) ra[p] = *reinterpret_cast<const vec_t*>(ga + (int64_t)(32 * p) * lda + ko);
+#pragma unroll
+      for (int p = 0; p < PB; ++p) rb[p] = *reinterpret_cast<const vec_t*>(gb + (int64_t)(32 * p) * ldb + ko);
+    };
 
-#pragma unroll
-    for (int p = 0; p < PA; ++p) ra[p] = *reinterpret_cast<const vec_t*>(ga + (int64_t)(32 * p) * lda);
-#pragma unroll
-    for (int p = 0; p < PB; ++p) rb[p] = *reinterpret_cast<const vec_t*>(gb + (int64_t)(32 * p) * ldb);
+    gload(0);
 #pragma unroll
     for (int p = 0; p < PA; ++p) *reinterpret_cast<vec_t*>(smem + wpos + 32 * p * ROWB) = ra[p];
 #pragma unroll
     for (int p = 0; p < PB; ++p) *reinterpret_cast<vec_t*>(smem + A_BYTES + wpos + 32 * p * ROWB) = rb[p];
     __syncthreads();
 
+    // (the f64 128x128 tile has no registers left for a second fragment set: it keeps the plain loop)
+    constexpr bool can_pipe = SMN_PIPE && MODE != 0 && STAGES == 2 && M::KG >= 2 && !(sizeof(T) == 8 && MT * NT >= 16);
+    if (can_pipe && (MODE == 1 ? nk >= 1 : nk >= 8)) {
+      constexpr int KG = M::KG;
+      constexpr int WG = KG >= 4 ? 1 : 0;             // group whose MFMAs the staging writes are spread between
+      constexpr int NW = PA + PB;                     // staging writes per thread per K-step
+      constexpr int NMM = MT * NT;                    // MFMA tiles per group
+      // The loop body is branch-free: the last K-step also runs its barrier, its "next" fragment reads, its staging writes
+      // (into the stage nobody reads any more) and global loads (clamped to the last valid K-step).  Those redundant loads
+      // are waited for by the next staging writes, which costs short loops more than the pipelining buys them: K-loops
+      // of fewer than 8 steps take the plain loop below.
+      const int last = nk - 1;
+      gload(1 < last ? 1 : last);
+      vec_t fa[2][MT], fb[2][NT];
+      frag_load(smem, 0, lane, wr, wc, fa[0], fb[0]);
+      for (int kt = 0; kt < nk; ++kt) {
+        const char* stage = smem + (kt & 1) * STAGE;
+        char* nstage = smem + ((kt + 1) & 1) * STAGE;
+#pragma unroll
+        for (int g = 0; g < KG; ++g) {
+          const int cur = g & 1, nxt = cur ^ 1;
+          if (g + 1 < KG) {
+            frag_load(stage, g + 1, lane, wr, wc, fa[nxt], fb[nxt]);
+          } else {
+            // Every read of THIS stage must be issued before the barrier: a faster wave overwrites it one group into the
+            // next K-step.  The last group's fragments were read a group ago; the empty asm consumes them here so that no
+            // compiler pass can sink those reads past the barrier.
+#pragma unroll
+            for (int m = 0; m < MT; ++m) asm volatile("" : "+v"(fa[cur][m]));
+#pragma unroll
+            for (int n = 0; n < NT; ++n) asm volatile("" : "+v"(fb[cur][n]));
+            __syncthreads();                           // in front of the last group's MFMAs (see above)
+            frag_load(nstage, 0, lane, wr, wc, fa[nxt], fb[nxt]);
+            gload(kt + 2 < last ? kt + 2 : last);    // clamped, not branched around: with a branch here the compiler sank
+          }                                            // the previous group's fragment reads below the barrier (a race)
+          // sched_barrier(0): the compiler's scheduler otherwise sinks the reads back down in front of their first use
+          // and gathers the staging writes behind the last MFMA -- the very bubbles this loop is written to remove
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int j = 0; j < NMM; ++j) {
+            M::mma(acc[j / NT][j % NT], fa[cur][j / NT], fb[cur][j % NT]);
+            if (g == WG) {
+              // the NW staging writes of the next stage, spread over the NMM tile products of this group
+#pragma unroll
+              for (int w = 0; w < NW; ++w) {
+                if (w >= (j * NW) / NMM && w < ((j + 1) * NW) / NMM) {
+                  if (w < PA) *reinterpret_cast<vec_t*>(nstage + wpos + 32 * w * ROWB) = ra[w < PA ? w : 0];
+                  else *reinterpret_cast<vec_t*>(nstage + A_BYTES + wpos + 32 * (w - PA) * ROWB) = rb[w >= PA ? w - PA : 0];
+                }
+              }
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      __syncthreads();
+      return;
+    }
+
+    if (can_pipe && MODE == 1) return;   // (nk == 0: nothing to add; the prologue barrier has run)
     for (int kt = 0; kt < nk; ++kt) {
       const bool more = kt + 1 < nk;
-      if (more) {
-        const int ko = (kt + 1) * M::BK;
-#pragma unroll
-        for (int p = 0; p < PA; ++p)
-          ra[p] = *reinterpret_cast<const vec_t*>(ga + (int64_t)(32 * p) * lda + ko);
-#pragma unroll
-        for (int p = 0; p < PB; ++p)
-          rb[p] = *reinterpret_cast<const vec_t*>(gb + (int64_t)(32 * p) * ldb + ko);
-      }
+      if (more) gload(kt + 1);
       compute(smem + (STAGES == 2 ? (kt & 1) * STAGE : 0), lane, wr, wc);
       if (more) {
         if (STAGES == 1) __syncthreads();   // every wave is done reading the only buffer
