@@ -19,4 +19,4 @@ golden:           ## regenerate tests/golden/nngp_golden.npz from the oracle
 	$(PY) tests/golden/make_golden.py
 
 clean:
-	rm -rf scale-mixtures-of-neural-network-gaussian-processes_amd/build* scale-mixtures-of-neural-network-gaussian-processes_amd/*.so scratch/bf16x3/*.so
+	rm -rf scale-mixtures-of-neural-network-gaussian-processes_amd/build* scale-mixtures-of-neural-network-gaussian-processes_amd/*.so scratch/bf16x3/*.so scratch/valu_rate/valu_rate scratch/dpp_probe/dpp_probe
