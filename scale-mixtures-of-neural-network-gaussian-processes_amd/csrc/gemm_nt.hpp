@@ -138,6 +138,11 @@ struct TileNT {
 #ifndef SMN_PIPE
 #define SMN_PIPE 1
 #endif
+  // SMN_PIPE_F64_BIG=1: the f64 128x128 tile takes the pipelined loop too -- it spills 164 B inside the loop and the fp64
+  // N=8192 step goes 12.37 -> 12.75 ms (scratch/f64big_ab.sh), so it stays on the plain loop.
+#ifndef SMN_PIPE_F64_BIG
+#define SMN_PIPE_F64_BIG 0
+#endif
   __device__ __forceinline__ void frag_load(const char* stage, int g, int lane, int wr, int wc, vec_t (&a)[MT], vec_t (&b)[NT]) {
     const char* sa = stage + (wr * WM) * ROWB;
     const char* sb = stage + A_BYTES + (wc * WN) * ROWB;
@@ -178,7 +183,7 @@ struct TileNT {
     __syncthreads();
 
     // (the f64 128x128 tile has no registers left for a second fragment set: it keeps the plain loop)
-    constexpr bool can_pipe = SMN_PIPE && MODE != 0 && STAGES == 2 && M::KG >= 2 && !(sizeof(T) == 8 && MT * NT >= 16);
+    constexpr bool can_pipe = SMN_PIPE && MODE != 0 && STAGES == 2 && M::KG >= 2 && !(SMN_PIPE_F64_BIG == 0 && sizeof(T) == 8 && MT * NT >= 16);
     if (can_pipe && (MODE == 1 ? nk >= 1 : nk >= 8)) {
       constexpr int KG = M::KG;
       constexpr int WG = KG >= 4 ? 1 : 0;             // group whose MFMAs the staging writes are spread between
