@@ -236,13 +236,16 @@ extern "C" int smn_ctx_create(int device_id, smn_ctx** out) {
   else main_ok = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_hi) == hipSuccess;
   if (const char* e = getenv("SMN_CHAIN_CUS")) c->chain_cus = atoi(e);
   if (const char* e = getenv("SMN_CHAIN_MIN_N")) c->chain_min_n = atol(e);
+  if (const char* e = getenv("SMN_F0_SPLIT")) c->f0_split = atoi(e);
   if (c->chain_cus > 0 && c->chain_cus < c->num_cu) {
     if (!masked_stream(&c->stream_bulk, c->chain_cus, c->num_cu)) c->stream_bulk = nullptr;   // no look-ahead then
+    if (c->stream_bulk && !masked_stream(&c->stream_bulk2, c->chain_cus, c->num_cu)) c->stream_bulk2 = nullptr;
   }
   bool ok = main_ok &&
             hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_hi) == hipSuccess &&
             hipEventCreateWithFlags(&c->ev_a, hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&c->ev_b, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&c->ev_c, hipEventDisableTiming) == hipSuccess &&
             hipEventCreate(&c->ev_t0) == hipSuccess && hipEventCreate(&c->ev_t1) == hipSuccess &&
             hipMalloc(reinterpret_cast<void**>(&c->d_scal), 64 * sizeof(double)) == hipSuccess &&
             hipMalloc(reinterpret_cast<void**>(&c->d_info), 16 * sizeof(int)) == hipSuccess &&
@@ -269,11 +272,13 @@ extern "C" int smn_ctx_destroy(smn_ctx* c) {
   if (c->h_mail) (void)hipHostFree(c->h_mail);
   if (c->ev_a) (void)hipEventDestroy(c->ev_a);
   if (c->ev_b) (void)hipEventDestroy(c->ev_b);
+  if (c->ev_c) (void)hipEventDestroy(c->ev_c);
   if (c->ev_t0) (void)hipEventDestroy(c->ev_t0);
   if (c->ev_t1) (void)hipEventDestroy(c->ev_t1);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
   if (c->stream_bulk) (void)hipStreamDestroy(c->stream_bulk);
+  if (c->stream_bulk2) (void)hipStreamDestroy(c->stream_bulk2);
   delete c;
   return SMN_OK;
 }

@@ -768,7 +768,9 @@ int cholesky_t(smn_ctx* ctx, T* a, int64_t n_total, int64_t n_factor, int64_t ld
   const int64_t S = ctx->super_panel / W * W;
   if (!la && S > W) {
     hipStream_t sb = n_total >= ctx->chain_min_n ? ctx->stream_bulk : nullptr;   // look-ahead across super-panels
+    hipStream_t sb2 = (sb && ctx->f0_split) ? ctx->stream_bulk2 : nullptr;
     bool bulk_busy = false;
+    bool f0b_pending = false;   // the deferred part of F0 (below) is in flight on sb2
     for (int64_t s0 = 0; s0 < n_factor; s0 += S) {
       const int64_t s_end = (n_factor - s0 < S) ? n_factor : s0 + S;
       for (int64_t j0 = s0; j0 < s_end; j0 += W) {
@@ -779,8 +781,17 @@ int cholesky_t(smn_ctx* ctx, T* a, int64_t n_total, int64_t n_factor, int64_t ld
           SMN_TRY(launch_panel<T>(ctx, st, a, lda, js, n_total, 0));
         }
         const int64_t j1 = j0 + w;
-        if (j1 < s_end)   // near update: columns [j1, s_end), all rows from the diagonal down
+        if (j1 < s_end) {   // near update: columns [j1, s_end), all rows from the diagonal down
+          if (f0b_pending) {   // it writes the tiles the deferred part of the previous F0 writes
+            SMN_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_c, 0));
+            f0b_pending = false;
+          }
           SMN_TRY(launch_update<T>(ctx, st, a, lda, j1, j1, j0, (int)w, (n_total - j1) / kTile, (s_end - j1) / kTile, 2));
+        }
+      }
+      if (f0b_pending) {   // a super-panel of one outer panel: nothing above waited
+        SMN_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_c, 0));
+        f0b_pending = false;
       }
       if (s_end < n_total && !sb) {   // far update: K = s_end - s0
         const int64_t tm = (n_total - s_end) / kTile;
@@ -795,9 +806,25 @@ int cholesky_t(smn_ctx* ctx, T* a, int64_t n_total, int64_t n_factor, int64_t ld
         SMN_HIP(ctx, hipEventRecord(ctx->ev_a, st));
         SMN_HIP(ctx, hipStreamWaitEvent(sb, ctx->ev_a, 0));
         if (bulk_busy) SMN_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_b, 0));
-        if (s_next > s_end)
-          SMN_TRY(launch_update<T>(ctx, st, a, lda, s_end, s_end, s0, (int)(s_end - s0), (n_total - s_end) / kTile,
-                                   (s_next - s_end) / kTile, 2));
+        if (s_next > s_end) {
+          // SMN_F0_SPLIT=1 (off by default): F0 again in two -- the next super-panel's FIRST outer panel (2 tile columns) is
+          // all its first panels need, so only that stays on the chain's stream; the other tile columns go to a second
+          // masked stream and run beside those panels; the first near update of the next super-panel writes the same
+          // tiles and waits (above).  Same bits, but 0.4 ms slower at C4 (profiles/r01f_f0_split_ab.txt): the deferred
+          // part shares the masked CUs with F1 and finishes later than the whole F0 did at high priority on all CUs.
+          const int64_t tn0 = (s_next - s_end) / kTile, tm0 = (n_total - s_end) / kTile;
+          const int64_t na = W / kTile;
+          if (sb2 && tn0 > na && tm0 > na) {
+            if (bulk_busy) SMN_HIP(ctx, hipStreamWaitEvent(sb2, ctx->ev_b, 0));
+            SMN_HIP(ctx, hipStreamWaitEvent(sb2, ctx->ev_a, 0));
+            SMN_TRY(launch_update<T>(ctx, st, a, lda, s_end, s_end, s0, (int)(s_end - s0), tm0, na, 2));
+            SMN_TRY(launch_update<T>(ctx, sb2, a, lda, s_end + W, s_end + W, s0, (int)(s_end - s0), tm0 - na, tn0 - na, 2));
+            SMN_HIP(ctx, hipEventRecord(ctx->ev_c, sb2));
+            f0b_pending = true;
+          } else {
+            SMN_TRY(launch_update<T>(ctx, st, a, lda, s_end, s_end, s0, (int)(s_end - s0), tm0, tn0, 2));
+          }
+        }
         if (n_total > s_next) {
           const int64_t tm = (n_total - s_next) / kTile;
           SMN_TRY(launch_update<T>(ctx, sb, a, lda, s_next, s_next, s0, (int)(s_end - s0), tm, tm, 1));

@@ -584,6 +584,7 @@ def test_cholesky_more_workgroups_than_cus_and_lookahead(L, ctx, dtype, n, m):
     {"SMN_XCD_MAP": "1"},
     {"SMN_HALF_TILES": "0"},                                   # no 64-row tiles for the small launches
     {"SMN_HALF_TILES": "100000"},                              # 64-row tiles everywhere
+    {"SMN_F0_SPLIT": "1"},                                     # third level of look-ahead: F0 in two, on two streams
     {"SMN_QUARTER_TILES": "0"},                                # no 64x64 tiles for the smallest launches
     {"SMN_QUARTER_TILES": "100000"},                           # 64x64 tiles everywhere
 ])
