@@ -239,7 +239,10 @@ extern "C" int smn_ctx_create(int device_id, smn_ctx** out) {
   if (const char* e = getenv("SMN_F0_SPLIT")) c->f0_split = atoi(e);
   if (c->chain_cus > 0 && c->chain_cus < c->num_cu) {
     if (!masked_stream(&c->stream_bulk, c->chain_cus, c->num_cu)) c->stream_bulk = nullptr;   // no look-ahead then
-    if (c->stream_bulk && !masked_stream(&c->stream_bulk2, c->chain_cus, c->num_cu)) c->stream_bulk2 = nullptr;
+    if (const char* e = getenv("SMN_CHAIN_CUS2")) c->chain_cus2 = atoi(e);
+    if (const char* e = getenv("SMN_BULK2_TILES")) c->bulk2_tiles = atol(e);
+    if (c->chain_cus2 <= 0 || c->chain_cus2 >= c->num_cu) c->chain_cus2 = c->chain_cus;
+    if (c->stream_bulk && !masked_stream(&c->stream_bulk2, c->chain_cus2, c->num_cu)) c->stream_bulk2 = nullptr;
   }
   bool ok = main_ok &&
             hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_hi) == hipSuccess &&

@@ -827,8 +827,14 @@ int cholesky_t(smn_ctx* ctx, T* a, int64_t n_total, int64_t n_factor, int64_t ld
         }
         if (n_total > s_next) {
           const int64_t tm = (n_total - s_next) / kTile;
-          SMN_TRY(launch_update<T>(ctx, sb, a, lda, s_next, s_next, s0, (int)(s_end - s0), tm, tm, 1));
-          SMN_HIP(ctx, hipEventRecord(ctx->ev_b, sb));
+          // late far updates (the chain is the longer pipeline by then) may go to the stream that leaves MORE CUs alone
+          hipStream_t sf = (ctx->stream_bulk2 && tm * (tm + 1) / 2 <= ctx->bulk2_tiles) ? ctx->stream_bulk2 : sb;
+          if (sf != sb) {
+            SMN_HIP(ctx, hipStreamWaitEvent(sf, ctx->ev_a, 0));
+            if (bulk_busy) SMN_HIP(ctx, hipStreamWaitEvent(sf, ctx->ev_b, 0));   // F1(s-1) wrote the same tiles
+          }
+          SMN_TRY(launch_update<T>(ctx, sf, a, lda, s_next, s_next, s0, (int)(s_end - s0), tm, tm, 1));
+          SMN_HIP(ctx, hipEventRecord(ctx->ev_b, sf));
           bulk_busy = true;
         }
       }

@@ -18,7 +18,9 @@ struct smn_ctx {
   hipStream_t stream = nullptr;   // main stream (high priority): every public call is ordered on it
   hipStream_t stream2 = nullptr;  // chain stream of the older one-level look-ahead (SMN_LOOKAHEAD=1)
   hipStream_t stream_bulk = nullptr;  // CU-masked stream of the far updates: may not use the first chain_cus CUs
-  hipStream_t stream_bulk2 = nullptr; // same mask: the part of F0 that the next super-panel's first outer panel does not need
+  hipStream_t stream_bulk2 = nullptr; // a second masked stream that leaves chain_cus2 CUs alone: late (chain-bound) far updates
+  int chain_cus2 = 32;                // env SMN_CHAIN_CUS2
+  int64_t bulk2_tiles = 0;            // far updates of at most this many tiles go to stream_bulk2 (env SMN_BULK2_TILES; 0: never)
   hipEvent_t ev_c = nullptr;          // ... and its completion
   int f0_split = 0;                   // env SMN_F0_SPLIT=1: third level of look-ahead (cholesky.hip); measured 0.4 ms SLOWER at C4
   int chain_cus = 32;                 // CUs kept free for the panel chain (env SMN_CHAIN_CUS; 0 = no look-ahead)
