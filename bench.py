@@ -40,67 +40,13 @@ def parse():
     p.add_argument("--act", default="relu")
     p.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     p.add_argument("--eps", type=float, default=None)
-    p.add_argument("--cpu-sample-n", type=int, default=12288)
+    p.add_argument("--cpu-sample-n", type=int, default=0, help="0: the benched N")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-recursion-probe", action="store_true")
     p.add_argument("--no-exclusive-probe", action="store_true", help="skip the look-ahead-off pass that fills frac_exclusive")
     p.add_argument("--sharded-path", action="store_true",
                    help="run the N>1 step (row shard + all-gather + LML) even with one rank (rehearsal on one GPU)")
     return p.parse_args()
-
-
-def cholesky_launch_model(n_total, n_factor):
-    """Flops EXECUTED by the trailing / strip update launches of csrc/cholesky.hip (full 128x128 tiles)."""
-    trail = strip = 0.0
-    n_trail = n_strip = 0
-    W = 2 * TILE
-    la = os.environ.get("SMN_LOOKAHEAD", "0") == "1"
-    S = int(os.environ.get("SMN_SUPER", "1024")) // W * W
-    if not la and S > W:                     # two-level schedule: near trapezoids (K=256) + far updates (K=S)
-        s0 = 0
-        while s0 < n_factor:
-            s_end = n_factor if n_factor - s0 < S else s0 + S
-            j0 = s0
-            while j0 < s_end:
-                w = min(W, s_end - j0)
-                js = j0 + TILE
-                while js < j0 + w:
-                    strip += ((n_total - js) // TILE) * TILE * TILE * 2.0 * (js - j0)
-                    n_strip += 1
-                    js += TILE
-                j1 = j0 + w
-                if j1 < s_end:
-                    tm, tn = (n_total - j1) // TILE, (s_end - j1) // TILE
-                    trail += (tn * (tn + 1) // 2 + (tm - tn) * tn) * TILE * TILE * 2.0 * w
-                    n_trail += 1
-                j0 += W
-            if s_end < n_total:
-                t = (n_total - s_end) // TILE
-                trail += (t * (t + 1) // 2) * TILE * TILE * 2.0 * (s_end - s0)
-                n_trail += 1
-            s0 += S
-        return trail, n_trail, strip, n_strip
-    j0 = 0
-    while j0 < n_factor:
-        w = min(W, n_factor - j0)
-        js = j0
-        while js < j0 + w:
-            if js > j0:
-                strip += ((n_total - js) // TILE) * TILE * TILE * 2.0 * (js - j0)
-                n_strip += 1
-            js += TILE
-        j1 = j0 + w
-        if j1 < n_total:
-            t = (n_total - j1) // TILE
-            if os.environ.get("SMN_LOOKAHEAD", "0") == "1" and j1 < n_factor and t > 2:
-                # look-ahead split: T0 = 2 full tile columns, T_rest = lower tiles
-                trail += (2 * t + (t - 2) * (t - 1) // 2) * TILE * TILE * 2.0 * w
-                n_trail += 2
-            else:
-                trail += (t * (t + 1) // 2) * TILE * TILE * 2.0 * w
-                n_trail += 1
-        j0 += W
-    return trail, n_trail, strip, n_strip
 
 
 def pmc_traffic(args, sharded):
@@ -115,60 +61,34 @@ def pmc_traffic(args, sharded):
         return None
 
 
-def cpu_baseline(args, np_dtype, eps):
-    """The CPU oracle (NumPy/SciPy port of the same math) on a bounded sample of the workload."""
-    import scipy.linalg as sla
-    from oracle import nngp_oracle as O
-    try:
-        from threadpoolctl import threadpool_info
-        threads = max([i.get("num_threads", 1) for i in threadpool_info()] or [1])
-    except Exception:
-        threads = os.cpu_count() or 1
-    ns = min(args.cpu_sample_n, args.n)
+def cpu_baseline(args, np_dtype, eps, gpu_logpdf=None):
+    """The CPU oracle (NumPy/SciPy port of the same math) on the benched workload, or a bounded sample of it
+    (--cpu-sample-n), on this box's host cores.  Also the checker of the headline number: the oracle's log-pdf and
+    its relative difference to the GPU's (same inputs, same dtype) go into the line when N is the benched N."""
+    from oracle import host_parallel as HP       # test infrastructure: imported by this leg only
+    ns = min(args.cpu_sample_n or args.n, args.n)
     rng = np.random.default_rng(0)
-    x = rng.standard_normal((ns, args.d)).astype(np_dtype)
-    y = rng.standard_normal(ns).astype(np_dtype)
+    x = rng.standard_normal((args.n, args.d)).astype(np_dtype)[:ns]     # the GPU's inputs (same seed, same draw order)
+    y = rng.standard_normal(args.n).astype(np_dtype)[:ns]
+    cores = HP.host_cores()
     # The oracle's maps are NumPy ufunc chains (single-threaded); the reference's CPU path (JAX/XLA) spreads its
     # elementwise work over the host cores.  Same oracle functions, applied to row blocks on a thread pool (ufuncs
     # release the GIL); the Gram and the factorisation go to the multi-threaded BLAS/LAPACK as they stand.
-    from concurrent.futures import ThreadPoolExecutor
-    try:
-        cores = len(os.sched_getaffinity(0))       # the CPU share this process may really use
-    except AttributeError:
-        cores = os.cpu_count() or 1
-    cores = max(1, min(cores, 64))
-    amap = O.get_act(args.act)
-    t0 = time.perf_counter()
-    k, q, _ = O.input_gram(x, None)
-    q = q.astype(np_dtype)
-
-    def rows(r0):
-        r1 = min(ns, r0 + 256)
-        kb, q1, q2 = k[r0:r1], q[r0:r1], q
-        for _ in range(args.layers):
-            kb, q1, q2, _t = O._dense(kb, q1, q2, None, 1.0, 1e-8)
-            kb, q1, q2, _t = amap(kb, q1, q2, None)
-        kb, q1, q2, _t = O._dense(kb, q1, q2, None, 1.0, 0.0)
-        k[r0:r1] = kb
-        return q1
-
-    with ThreadPoolExecutor(max_workers=cores) as ex:
-        qd = np.concatenate(list(ex.map(rows, range(0, ns, 256))))
-    k[np.diag_indices(ns)] = qd                    # exact diagonal, like O.mlp_kernel's symmetric case
-    threads = max(threads, cores)
-    t1 = time.perf_counter()
-    k[np.diag_indices(ns)] += np_dtype(eps)
-    l = sla.cholesky(k, lower=True, overwrite_a=True, check_finite=False)
-    z = sla.solve_triangular(l, y, lower=True, check_finite=False)
-    lp = -0.5 * float(z @ z) - ns / 2 * np.log(2 * np.pi) - float(np.log(np.diag(l)).sum())
-    t2 = time.perf_counter()
+    k, t_build = HP.mlp_kernel_rows_threaded(x, args.layers, args.act, 1.0, 1e-8, 1.0, dtype=np_dtype, cores=cores)
+    lp, quad, logdet, t_chol = HP.gaussian_lml(k, y, eps)
+    del k
     flops = 2.0 * ns * ns * args.d + ns ** 3 / 3.0
-    return {
-        "value": flops / (t2 - t0) / 1e9, "unit": "GFLOP/s", "cores": int(threads), "kind": "port",
-        "sample": "same workload at N=%d (d=%d, L=%d %s, %s): NumPy/SciPy oracle (layer maps on a %d-thread pool), build %.2f s + Cholesky/LML %.2f s"
-                  % (ns, args.d, args.layers, args.act, np.dtype(np_dtype).name, cores, t1 - t0, t2 - t1),
-        "logpdf_finite": bool(np.isfinite(lp)),
+    out = {
+        "value": flops / (t_build + t_chol) / 1e9, "unit": "GFLOP/s", "cores": int(cores), "kind": "port",
+        "sample": "%s N=%d (d=%d, L=%d %s, %s): NumPy/SciPy oracle (layer maps on a %d-thread pool), build %.2f s + Cholesky/LML %.2f s"
+                  % ("the benched workload," if ns == args.n else "same workload at", ns, args.d, args.layers, args.act,
+                     np.dtype(np_dtype).name, cores, t_build, t_chol),
+        "cpu_logpdf": lp, "cpu_logdet": logdet,
     }
+    if ns == args.n and gpu_logpdf is not None:
+        out["gpu_logpdf"] = gpu_logpdf
+        out["rel_diff_vs_gpu"] = abs(gpu_logpdf - lp) / abs(lp)
+    return out
 
 
 class _JsonOut:
@@ -281,6 +201,12 @@ def main():
     ms, cnt = C.c_double(), C.c_int()
     ctx.call("smn_profile_read", 5, C.byref(ms), C.byref(cnt))
     trail_timed = (ms.value / max(args.steps, 1), cnt.value // max(args.steps, 1))
+    # MFMA flops the library EXECUTED (whole tiles, counted as the launches are issued) per step, by category
+    fl = {}
+    for cat in (4, 5):
+        v = C.c_double()
+        ctx.call("smn_profile_flops", cat, C.byref(v))
+        fl[cat] = v.value / max(args.steps, 1)
     DETAIL_STEPS = 2
     ctx.call("smn_profile_enable", 1)              # untimed detail pass: every category
     for _ in range(DETAIL_STEPS):
@@ -303,7 +229,7 @@ def main():
     if rank == 0:
         n_total = n + TILE if world == 1 else n + TILE
         flops_counted = 2.0 * n * n * d + n ** 3 / 3.0                 # Gram 2N^2 d + Cholesky N^3/3
-        trail_fl, n_trail, strip_fl, n_strip = cholesky_launch_model(n_total, n)
+        trail_fl, strip_fl = fl[5], fl[4]
         peak = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_F64_MFMA_TFLOPS
         per = prof                                 # per step: `trail` from the timed region, the rest from the detail pass
         kp = ((d + 31) // 32 * 32) if args.dtype == "f32" else ((d + 15) // 16 * 16)
@@ -337,9 +263,8 @@ def main():
         # Look-ahead (default from N=8192): the far updates run on a CU-masked stream (num_cu - SMN_CHAIN_CUS CUs)
         # BESIDE the next super-panel's panel chain, so the launch durations above overlap with other kernels and
         # `frac` (kept as the contract defines it) understates the kernel.  Two more readings of the same kernel:
-        chain_cus = int(os.environ.get("SMN_CHAIN_CUS", "32"))
-        lookahead = chain_cus > 0 and n_total >= int(os.environ.get("SMN_CHAIN_MIN_N", "8192")) and \
-            os.environ.get("SMN_LOOKAHEAD", "0") != "1"
+        min_n_env = os.environ.get("SMN_CHAIN_MIN_N")
+        lookahead = n_total >= int(min_n_env or "8192")
         chol_wall_ms = ms_per_step - per["build"][0] - per["prep"][0] - per["misc"][0]
         if not sharded:
             roof["cholesky_wall_ms"] = chol_wall_ms
@@ -347,10 +272,10 @@ def main():
             roof["cholesky_mfma_frac"] = (trail_fl + strip_fl) / (chol_wall_ms * 1e-3) / 1e12 / peak
         roof["lookahead"] = bool(lookahead)
         if lookahead and not sharded and not args.no_exclusive_probe:
-            # the same launches with the look-ahead off (nothing else on the GPU): an untimed extra pass on a second
-            # context created with SMN_CHAIN_CUS=0
+            # the same launches with the look-ahead off (one stream, nothing else on the GPU): an untimed extra pass on a
+            # second context created with SMN_CHAIN_MIN_N out of reach
             try:
-                os.environ["SMN_CHAIN_CUS"] = "0"
+                os.environ["SMN_CHAIN_MIN_N"] = "1000000000"
                 ctx2 = L.Context(local_rank)
                 x2 = ctx2.to_device(x.numpy()); y2 = ctx2.to_device(y.numpy())
 
@@ -373,10 +298,10 @@ def main():
                 roof["frac_exclusive"] = None
                 roof["exclusive_error"] = str(e)
             finally:
-                if chain_cus == 32 and "SMN_CHAIN_CUS" in os.environ:
-                    del os.environ["SMN_CHAIN_CUS"]
+                if min_n_env is None:
+                    del os.environ["SMN_CHAIN_MIN_N"]
                 else:
-                    os.environ["SMN_CHAIN_CUS"] = str(chain_cus)
+                    os.environ["SMN_CHAIN_MIN_N"] = min_n_env
         others = {}
         if per["build"][0] > 0:
             others["build_kernel (fused Gram + %d-layer recursion, executed tiles)" % nl] = {
@@ -437,7 +362,7 @@ def main():
                 others["recursion_kernel"] = {"error": str(e)}
         out["roofline_other_kernels"] = others
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args, np_dtype, eps)
+            out["cpu_baseline"] = cpu_baseline(args, np_dtype, eps, lp.value)
         elif world == 1:
             out["cpu_baseline"] = None
         out_fd.emit(json.dumps(out))

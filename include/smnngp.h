@@ -67,6 +67,10 @@ int smn_timer_stop_ms(smn_ctx* ctx, double* ms);           /* synchronises */
  * than timing all ~280 launches of it. */
 int smn_profile_enable(smn_ctx* ctx, int on);
 int smn_profile_read(smn_ctx* ctx, int category, double* total_ms, int* launches);
+/* MFMA flops the launches of a category have EXECUTED since the last smn_profile_enable (whole 128x128 tiles, counted
+ * on the host as they are issued): 4 strip updates, 5 trailing updates.  What a roofline
+ * fraction of those kernels is priced with. */
+int smn_profile_flops(smn_ctx* ctx, int category, double* flops);
 
 /* ---- NNGP / NTK kernel build ----
  * Replaces kernel_fn(x1, x2, get) produced by get_mlp_kernel / get_dense_resnet_kernel

@@ -61,6 +61,7 @@ PROTOTYPES = {
     "smn_timer_stop_ms": [_vp, _pd],
     "smn_profile_enable": [_vp, _i],
     "smn_profile_read": [_vp, _i, _pd, _pi],
+    "smn_profile_flops": [_vp, _i, _pd],
     "smn_kernel_mlp": [_vp, _i, _i, _i, _i, _d, _d, _d, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _i, _i, _vp, _vp, _i64],
     "smn_kernel_mlp_rows": [_vp, _i, _i, _i, _i, _d, _d, _d, _vp, _i64, _i64, _i64, _i64, _i64, _i, _vp, _vp, _i64],
     "smn_kernel_mlp_lower_rows": [_vp, _i, _i, _i, _i, _d, _d, _d, _vp, _i64, _i64, _i64, _i64, _i64, _i, _vp, _vp, _i64],
@@ -264,9 +265,20 @@ class DeviceArray:
 
 
 def as_device(x, ctx=None, dtype=None):
-    """numpy / DeviceArray -> DeviceArray (float32 stays float32, everything else becomes float64
-    unless `dtype` says otherwise)."""
+    """numpy / DeviceArray -> a plain DeviceArray whose raw pointer may be handed to the library (float32 stays
+    float32, everything else becomes float64 unless `dtype` says otherwise).
+
+    A DeviceArray argument is checked, not trusted: one that lives in another Context raises (its pointer belongs to
+    that context's device and stream); a lazy view `scale * A + shift * I` is materialised (the library would read A);
+    a dtype other than the requested one is converted (it would be read with the wrong element size).  Both
+    conversions go through the host: they are for small operands (x_test, y), large ones should arrive right."""
     if isinstance(x, DeviceArray):
+        if ctx is not None and x.ctx is not ctx:
+            raise ValueError("DeviceArray belongs to another Context (device %d) than the one in use (device %d)"
+                             % (x.ctx.device, ctx.device))
+        want = x.dtype if dtype is None else np.dtype(dtype)
+        if x.scale != 1.0 or x.shift != 0.0 or want != x.dtype:
+            return x.ctx.to_device(np.ascontiguousarray(x.numpy(), dtype=want))
         return x
     ctx = ctx or default_context()
     x = np.asarray(x)

@@ -205,7 +205,6 @@ extern "C" int smn_ctx_create(int device_id, smn_ctx** out) {
   if (hipSetDevice(device_id) != hipSuccess) return SMN_EHIP;
   smn_ctx* c = new smn_ctx();
   c->device = device_id;
-  if (const char* e = getenv("SMN_LOOKAHEAD")) c->lookahead = e[0] == '1';
   if (const char* e = getenv("SMN_XCD_MAP")) c->xcd_map = e[0] == '1';
   if (const char* e = getenv("SMN_PERSISTENT")) c->persistent_trail = e[0] != '0';
   if (const char* e = getenv("SMN_REC_SYM")) c->rec_sym = e[0] != '0';
@@ -214,41 +213,32 @@ extern "C" int smn_ctx_create(int device_id, smn_ctx** out) {
   if (const char* e = getenv("SMN_PERSIST_MAXK")) c->persist_max_k = atoi(e);
   if (const char* e = getenv("SMN_HALF_TILES")) c->half_tile_max = atoi(e);
   if (const char* e = getenv("SMN_QUARTER_TILES")) c->quarter_tile_max = atoi(e);
-  if (const char* e = getenv("SMN_PANEL_SMALL")) c->panel_small_rows = atoi(e);
   if (const char* e = getenv("SMN_SUPER")) c->super_panel = atol(e);
+  if (const char* e = getenv("SMN_PANEL_SMALL")) c->panel_small_rows = atoi(e);
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0)
       c->num_cu = prop.multiProcessorCount;
   }
-  int prio_lo = 0, prio_hi = 0;   // the look-ahead stream carries the critical path: highest priority
+  int prio_lo = 0, prio_hi = 0;   // the main stream carries the critical path (the panel chain): highest priority
   (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-  // CU-masked streams (experiments): SMN_MAIN_MASK_CUS=n restricts the main stream to the first n mask bits;
-  // SMN_CHAIN_CUS=r gives the Cholesky a "bulk" stream that may not use the first r mask bits, so the panel
-  // chain on stream2 always finds r CUs the trailing update cannot occupy.
+  // SMN_CHAIN_CUS=r gives the Cholesky a "bulk" stream that may not use the first r bits of the CU mask, so the panel
+  // chain on the main stream always finds r CUs the block updates cannot occupy (CU masks do restrict kernels on this
+  // stack: profiles/r01e_lookahead_ab_reserved_cus.txt).
   auto masked_stream = [&](hipStream_t* st, int lo, int hi) -> bool {
     uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int b = lo; b < hi && b < 256; ++b) mask[b >> 5] |= 1u << (b & 31);
     return hipExtStreamCreateWithCUMask(st, 8, mask) == hipSuccess;
   };
-  bool main_ok;
-  if (const char* e = getenv("SMN_MAIN_MASK_CUS")) main_ok = masked_stream(&c->stream, 0, atoi(e));
-  else main_ok = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_hi) == hipSuccess;
+  const bool main_ok = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_hi) == hipSuccess;
   if (const char* e = getenv("SMN_CHAIN_CUS")) c->chain_cus = atoi(e);
   if (const char* e = getenv("SMN_CHAIN_MIN_N")) c->chain_min_n = atol(e);
-  if (const char* e = getenv("SMN_F0_SPLIT")) c->f0_split = atoi(e);
   if (c->chain_cus > 0 && c->chain_cus < c->num_cu) {
     if (!masked_stream(&c->stream_bulk, c->chain_cus, c->num_cu)) c->stream_bulk = nullptr;   // no look-ahead then
-    if (const char* e = getenv("SMN_CHAIN_CUS2")) c->chain_cus2 = atoi(e);
-    if (const char* e = getenv("SMN_BULK2_TILES")) c->bulk2_tiles = atol(e);
-    if (c->chain_cus2 <= 0 || c->chain_cus2 >= c->num_cu) c->chain_cus2 = c->chain_cus;
-    if (c->stream_bulk && !masked_stream(&c->stream_bulk2, c->chain_cus2, c->num_cu)) c->stream_bulk2 = nullptr;
   }
   bool ok = main_ok &&
-            hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_hi) == hipSuccess &&
             hipEventCreateWithFlags(&c->ev_a, hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&c->ev_b, hipEventDisableTiming) == hipSuccess &&
-            hipEventCreateWithFlags(&c->ev_c, hipEventDisableTiming) == hipSuccess &&
             hipEventCreate(&c->ev_t0) == hipSuccess && hipEventCreate(&c->ev_t1) == hipSuccess &&
             hipMalloc(reinterpret_cast<void**>(&c->d_scal), 64 * sizeof(double)) == hipSuccess &&
             hipMalloc(reinterpret_cast<void**>(&c->d_info), 16 * sizeof(int)) == hipSuccess &&
@@ -265,6 +255,7 @@ extern "C" int smn_ctx_create(int device_id, smn_ctx** out) {
 extern "C" int smn_ctx_destroy(smn_ctx* c) {
   if (!c) return SMN_OK;
   (void)hipSetDevice(c->device);
+  if (c->stream_bulk) (void)hipStreamSynchronize(c->stream_bulk);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->comm) smn_comm_destroy(c);
   for (int i = 0; i < smn_ctx::kSlots; ++i)
@@ -275,13 +266,10 @@ extern "C" int smn_ctx_destroy(smn_ctx* c) {
   if (c->h_mail) (void)hipHostFree(c->h_mail);
   if (c->ev_a) (void)hipEventDestroy(c->ev_a);
   if (c->ev_b) (void)hipEventDestroy(c->ev_b);
-  if (c->ev_c) (void)hipEventDestroy(c->ev_c);
   if (c->ev_t0) (void)hipEventDestroy(c->ev_t0);
   if (c->ev_t1) (void)hipEventDestroy(c->ev_t1);
   if (c->stream) (void)hipStreamDestroy(c->stream);
-  if (c->stream2) (void)hipStreamDestroy(c->stream2);
   if (c->stream_bulk) (void)hipStreamDestroy(c->stream_bulk);
-  if (c->stream_bulk2) (void)hipStreamDestroy(c->stream_bulk2);
   delete c;
   return SMN_OK;
 }
@@ -294,12 +282,14 @@ extern "C" int smn_last_error(smn_ctx* ctx, char* buf, size_t n) {
 
 extern "C" int smn_synchronize(smn_ctx* ctx) {
   if (!ctx) return SMN_EINVAL;
+  SMN_ENTER(ctx);
   SMN_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return SMN_OK;
 }
 
 extern "C" int smn_malloc(smn_ctx* ctx, size_t bytes, void** dptr) {
   if (!ctx || !dptr) return SMN_EINVAL;
+  SMN_ENTER(ctx);
   *dptr = nullptr;
   if (bytes == 0) bytes = 16;
   SMN_HIP(ctx, hipMalloc(dptr, bytes));
@@ -308,6 +298,7 @@ extern "C" int smn_malloc(smn_ctx* ctx, size_t bytes, void** dptr) {
 
 extern "C" int smn_free(smn_ctx* ctx, void* dptr) {
   if (!ctx) return SMN_EINVAL;
+  SMN_ENTER(ctx);
   if (!dptr) return SMN_OK;
   SMN_HIP(ctx, hipStreamSynchronize(ctx->stream));
   SMN_HIP(ctx, hipFree(dptr));
@@ -316,12 +307,14 @@ extern "C" int smn_free(smn_ctx* ctx, void* dptr) {
 
 extern "C" int smn_memset(smn_ctx* ctx, void* dptr, int value, size_t bytes) {
   if (!ctx) return SMN_EINVAL;
+  SMN_ENTER(ctx);
   SMN_HIP(ctx, hipMemsetAsync(dptr, value, bytes, ctx->stream));
   return SMN_OK;
 }
 
 extern "C" int smn_memcpy_h2d(smn_ctx* ctx, void* dst, const void* src, size_t bytes) {
   if (!ctx) return SMN_EINVAL;
+  SMN_ENTER(ctx);
   SMN_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
   SMN_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return SMN_OK;
@@ -329,6 +322,7 @@ extern "C" int smn_memcpy_h2d(smn_ctx* ctx, void* dst, const void* src, size_t b
 
 extern "C" int smn_memcpy_d2h(smn_ctx* ctx, void* dst, const void* src, size_t bytes) {
   if (!ctx) return SMN_EINVAL;
+  SMN_ENTER(ctx);
   SMN_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
   SMN_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return SMN_OK;
@@ -336,6 +330,7 @@ extern "C" int smn_memcpy_d2h(smn_ctx* ctx, void* dst, const void* src, size_t b
 
 extern "C" int smn_memcpy_d2d(smn_ctx* ctx, void* dst, const void* src, size_t bytes) {
   if (!ctx) return SMN_EINVAL;
+  SMN_ENTER(ctx);
   SMN_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
   return SMN_OK;
 }
@@ -343,6 +338,7 @@ extern "C" int smn_memcpy_d2d(smn_ctx* ctx, void* dst, const void* src, size_t b
 extern "C" int smn_memcpy2d_h2d(smn_ctx* ctx, void* dst, size_t dpitch, const void* src, size_t spitch,
                                 size_t width_bytes, size_t rows) {
   if (!ctx) return SMN_EINVAL;
+  SMN_ENTER(ctx);
   SMN_HIP(ctx, hipMemcpy2DAsync(dst, dpitch, src, spitch, width_bytes, rows, hipMemcpyHostToDevice, ctx->stream));
   SMN_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return SMN_OK;
@@ -351,6 +347,7 @@ extern "C" int smn_memcpy2d_h2d(smn_ctx* ctx, void* dst, size_t dpitch, const vo
 extern "C" int smn_memcpy2d_d2h(smn_ctx* ctx, void* dst, size_t dpitch, const void* src, size_t spitch,
                                 size_t width_bytes, size_t rows) {
   if (!ctx) return SMN_EINVAL;
+  SMN_ENTER(ctx);
   SMN_HIP(ctx, hipMemcpy2DAsync(dst, dpitch, src, spitch, width_bytes, rows, hipMemcpyDeviceToHost, ctx->stream));
   SMN_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return SMN_OK;
@@ -358,12 +355,14 @@ extern "C" int smn_memcpy2d_d2h(smn_ctx* ctx, void* dst, size_t dpitch, const vo
 
 extern "C" int smn_timer_start(smn_ctx* ctx) {
   if (!ctx) return SMN_EINVAL;
+  SMN_ENTER(ctx);
   SMN_HIP(ctx, hipEventRecord(ctx->ev_t0, ctx->stream));
   return SMN_OK;
 }
 
 extern "C" int smn_timer_stop_ms(smn_ctx* ctx, double* ms) {
   if (!ctx || !ms) return SMN_EINVAL;
+  SMN_ENTER(ctx);
   SMN_HIP(ctx, hipEventRecord(ctx->ev_t1, ctx->stream));
   SMN_HIP(ctx, hipEventSynchronize(ctx->ev_t1));
   float f = 0.f;
@@ -375,16 +374,28 @@ extern "C" int smn_timer_stop_ms(smn_ctx* ctx, double* ms) {
 // ---- per-kernel timing hooks (bench.py's roofline numbers come from these hipEvents) ----
 extern "C" int smn_profile_enable(smn_ctx* ctx, int on) {
   if (!ctx) return SMN_EINVAL;
+  SMN_ENTER(ctx);
   SMN_HIP(ctx, hipStreamSynchronize(ctx->stream));
   ctx->prof = on != 0;
   ctx->prof_mask = on == 1 ? ~0u : ((unsigned)on >> 1);   // 1: every category; 2 << c: category c only (masks add)
   ctx->prof_used = 0;
   ctx->prof_cat.clear();
+  for (double& f : ctx->prof_flops) f = 0.0;
+  return SMN_OK;
+}
+
+// MFMA flops the launches of a category have EXECUTED since the last smn_profile_enable (whole tiles, counted on the
+// host as they are issued; categories 4 = strip update, 5 = trailing update): bench.py prices the dominant
+// kernel with this instead of re-deriving the schedule.
+extern "C" int smn_profile_flops(smn_ctx* ctx, int category, double* flops) {
+  if (!ctx || !flops || category < 0 || category >= PROF_NCAT) return SMN_EINVAL;
+  *flops = ctx->prof_flops[category];
   return SMN_OK;
 }
 
 extern "C" int smn_profile_read(smn_ctx* ctx, int category, double* total_ms, int* launches) {
   if (!ctx || category < 0 || category >= PROF_NCAT) return SMN_EINVAL;
+  SMN_ENTER(ctx);
   SMN_HIP(ctx, hipStreamSynchronize(ctx->stream));
   double tot = 0.0;
   int cnt = 0;

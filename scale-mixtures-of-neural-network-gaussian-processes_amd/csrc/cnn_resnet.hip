@@ -379,6 +379,7 @@ extern "C" int smn_kernel_conv_resnet(smn_ctx* ctx, int dtype, int act, int bloc
                                       double last_w_std, const void* x1_d, int64_t n1, const void* x2_d, int64_t n2,
                                       int64_t H, int64_t W, int64_t C, int fill, void* nngp_d, int64_t ldk) {
   if (!ctx || !x1_d || !nngp_d) return SMN_EINVAL;
+  SMN_ENTER(ctx);
   if (dtype != SMN_F32 && dtype != SMN_F64) return smn_fail(ctx, SMN_EINVAL, "bad dtype %d", dtype);
   if (act != SMN_ACT_RELU && act != SMN_ACT_ERF) return smn_fail(ctx, SMN_EINVAL, "Unsupported act %d", act);
   if (n1 <= 0 || (x2_d && n2 <= 0) || H <= 0 || W <= 0 || C <= 0 || block_size <= 0)

@@ -78,10 +78,10 @@ extern "C" int smn_comm_unique_id(char id_out[128]) {
 
 extern "C" int smn_comm_init(smn_ctx* ctx, int nranks, int rank, const char id[128]) {
   if (!ctx || !id || nranks <= 0 || rank < 0 || rank >= nranks) return SMN_EINVAL;
+  SMN_ENTER(ctx);
   Rccl& r = rccl();
   if (!r.ok) return smn_fail(ctx, SMN_ECOMM, "librccl.so could not be loaded");
   if (ctx->comm) return smn_fail(ctx, SMN_EINVAL, "communicator already initialised");
-  SMN_HIP(ctx, hipSetDevice(ctx->device));
   nccl_uid u;
   memcpy(u.internal, id, 128);
   nccl_comm c = nullptr;
@@ -95,6 +95,7 @@ extern "C" int smn_comm_init(smn_ctx* ctx, int nranks, int rank, const char id[1
 
 extern "C" int smn_comm_destroy(smn_ctx* ctx) {
   if (!ctx) return SMN_EINVAL;
+  SMN_ENTER(ctx);
   if (ctx->comm) {
     Rccl& r = rccl();
     if (r.ok) r.CommDestroy(static_cast<nccl_comm>(ctx->comm));
@@ -107,6 +108,7 @@ extern "C" int smn_comm_destroy(smn_ctx* ctx) {
 
 extern "C" int smn_allgather(smn_ctx* ctx, int dtype, const void* send_d, void* recv_d, int64_t count) {
   if (!ctx || !send_d || !recv_d || count <= 0) return SMN_EINVAL;
+  SMN_ENTER(ctx);
   if (dtype != SMN_F32 && dtype != SMN_F64) return smn_fail(ctx, SMN_EINVAL, "bad dtype");
   if (!ctx->comm) {  // single rank: the gather is a copy
     if (send_d != recv_d)
@@ -159,6 +161,7 @@ __global__ void unpack_blocks_kernel(const T* __restrict__ stage, int64_t chunk,
 extern "C" int smn_unpack_lower_blocks(smn_ctx* ctx, int dtype, const void* stage_d, int64_t n, int nranks,
                                        int64_t block_rows, void* k_d, int64_t ldk) {
   if (!ctx || !stage_d || !k_d) return SMN_EINVAL;
+  SMN_ENTER(ctx);
   if (dtype != SMN_F32 && dtype != SMN_F64) return smn_fail(ctx, SMN_EINVAL, "bad dtype");
   if (n <= 0 || nranks <= 0 || block_rows <= 0 || block_rows % kTile || ldk < n ||
       2 * (int64_t)nranks * block_rows < n)

@@ -15,14 +15,8 @@
 
 struct smn_ctx {
   int device = 0;
-  hipStream_t stream = nullptr;   // main stream (high priority): every public call is ordered on it
-  hipStream_t stream2 = nullptr;  // chain stream of the older one-level look-ahead (SMN_LOOKAHEAD=1)
-  hipStream_t stream_bulk = nullptr;  // CU-masked stream of the far updates: may not use the first chain_cus CUs
-  hipStream_t stream_bulk2 = nullptr; // a second masked stream that leaves chain_cus2 CUs alone: late (chain-bound) far updates
-  int chain_cus2 = 32;                // env SMN_CHAIN_CUS2
-  int64_t bulk2_tiles = 0;            // far updates of at most this many tiles go to stream_bulk2 (env SMN_BULK2_TILES; 0: never)
-  hipEvent_t ev_c = nullptr;          // ... and its completion
-  int f0_split = 0;                   // env SMN_F0_SPLIT=1: third level of look-ahead (cholesky.hip); measured 0.4 ms SLOWER at C4
+  hipStream_t stream = nullptr;       // main stream (high priority): every public call is ordered on it; carries the panel chain
+  hipStream_t stream_bulk = nullptr;  // CU-masked stream of the far updates F1: may not use the first chain_cus CUs
   int chain_cus = 32;                 // CUs kept free for the panel chain (env SMN_CHAIN_CUS; 0 = no look-ahead)
   int64_t chain_min_n = 8192;         // look-ahead only from this matrix size on (env SMN_CHAIN_MIN_N)
   hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
@@ -46,23 +40,22 @@ struct smn_ctx {
   std::vector<hipEvent_t> prof_ev;   // pool, used pairwise
   std::vector<int> prof_cat;         // category of pair i
   size_t prof_used = 0;              // events handed out
-  bool lookahead = false;            // older one-level look-ahead on stream2 (env SMN_LOOKAHEAD=1); the default look-ahead is chain_cus above
+  double prof_flops[8] = {};         // MFMA flops EXECUTED per category since smn_profile_enable (whole tiles; host-side count)
   int num_cu = 256;                  // hipDeviceProp_t::multiProcessorCount
-  int64_t super_panel = 1024;        // columns per super-panel of the two-level Cholesky (env SMN_SUPER; 0 = one level)
+  int64_t super_panel = 1024;        // columns per super-panel of the two-level Cholesky (env SMN_SUPER)
   // structural-zero hint for the factorisation in flight: appended rows [id0, id1) hold an identity block
   // (row id0 + i is zero left of column i), set by cholesky_padded, -1 = none
   int64_t chol_id0 = -1, chol_id1 = -1;
   bool lds_attrs_done[2] = {false, false};   // hipFuncSetAttribute(MaxDynamicSharedMemorySize) issued for f32 / f64 kernels
   int panel_small_rows = 4096;       // f32 panels with at most this many rows below use 64-row workgroups (env SMN_PANEL_SMALL)
-  int quarter_tile_max = 256;        // ... and with at most this many, 64x64 tiles (env SMN_QUARTER_TILES)
-  int half_tile_max = 384;           // trailing launches with at most this many 128x128 tiles use 64-row tiles (env SMN_HALF_TILES)
+  int quarter_tile_max = 256;        // update launches with at most this many 128x128 tiles use 64x64 tiles (env SMN_QUARTER_TILES)
+  int half_tile_max = 384;           // ... and with at most this many, 64-row tiles (env SMN_HALF_TILES)
   int persist_max_k = 512;           // largest K the persistent trailing kernel takes (env SMN_PERSIST_MAXK)
   int cnn_fast32 = 1;                // conv-NNGP: register-only 3x3 stencil for 32x32 images (env SMN_CNN_FAST32: 0 never, 1 fp64 only, 2 both)
   int cnn_tiled = 1;                 // conv-NNGP pair kernel: XCD-tiled pair order for large problems (env SMN_CNN_TILED: 0 never, 2 always)
   bool rec_sym = true;               // stand-alone recursion: lower-tile + mirror kernel when symmetric (env SMN_REC_SYM=0)
   bool persistent_trail = true;      // persistent trailing-update kernel (env SMN_PERSISTENT=0 disables)
-  bool xcd_map = false;              // XCD-aware patch tile order (env SMN_XCD_MAP=1): measured 2-6 % SLOWER
-                                     // than the linear order on C4 (profiles/README.md), so off by default
+  bool xcd_map = false;              // XCD-aware patch tile order (env SMN_XCD_MAP=1)
 };
 
 enum { PROF_PREP = 0, PROF_BUILD = 1, PROF_RECURSION = 2, PROF_PANEL = 3, PROF_STRIP = 4, PROF_TRAIL = 5,
@@ -116,6 +109,25 @@ inline int smn_fail(smn_ctx* ctx, int code, const char* fmt, ...) {
   } while (0)
 
 #define SMN_CHECK_LAUNCH(ctx) SMN_HIP(ctx, hipGetLastError())
+
+// The current HIP device is a property of the calling host THREAD (default 0), not of the context: allocations,
+// function attributes, events and plain launches all go to it.  Every C-ABI entry that takes a context therefore opens
+// with SMN_ENTER(ctx): it makes ctx->device current for the duration of the call and puts the caller's device back on
+// exit (worker threads of sweeps.py, two contexts on two devices in one thread, torch.cuda.set_device() after the
+// context was made).
+struct SmnDeviceGuard {
+  int prev = -1;
+  bool switched = false;
+  explicit SmnDeviceGuard(int dev) {
+    if (hipGetDevice(&prev) == hipSuccess && prev != dev) switched = hipSetDevice(dev) == hipSuccess;
+  }
+  ~SmnDeviceGuard() {
+    if (switched) (void)hipSetDevice(prev);
+  }
+  SmnDeviceGuard(const SmnDeviceGuard&) = delete;
+  SmnDeviceGuard& operator=(const SmnDeviceGuard&) = delete;
+};
+#define SMN_ENTER(ctx) SmnDeviceGuard smn_device_guard_((ctx)->device)
 
 inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 

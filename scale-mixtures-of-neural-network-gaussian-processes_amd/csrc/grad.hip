@@ -261,6 +261,7 @@ extern "C" int smn_lml_grad_terms(smn_ctx* ctx, int dtype, int net, int act, int
                                   const void* q_d, const void* neg_kinv_d, int64_t ldkinv, const void* alpha_d,
                                   double coef, double terms_h[4]) {
   if (!ctx || !k0_d || !q_d || !neg_kinv_d || !alpha_d || !terms_h) return SMN_EINVAL;
+  SMN_ENTER(ctx);
   if (dtype != SMN_F32 && dtype != SMN_F64) return smn_fail(ctx, SMN_EINVAL, "bad dtype");
   if (n <= 0 || ldk0 < n || ldkinv < n) return smn_fail(ctx, SMN_EINVAL, "smn_lml_grad_terms: bad sizes");
   if (net != SMN_NET_MLP && net != SMN_NET_DENSE_RESNET) return smn_fail(ctx, SMN_EINVAL, "unknown net %d", net);
@@ -280,6 +281,7 @@ extern "C" int smn_spr_loss_grad(smn_ctx* ctx, int dtype, int net, int act, int 
                                  const void* y_d, double eps_abs, double df, double scale, double* quad_h,
                                  double* logdet_h, int* info_h, double terms_h[4]) {
   if (!ctx || !x_d || !y_d || !terms_h) return SMN_EINVAL;
+  SMN_ENTER(ctx);
   if (dtype != SMN_F32 && dtype != SMN_F64) return smn_fail(ctx, SMN_EINVAL, "bad dtype");
   if (n <= 0 || d <= 0) return smn_fail(ctx, SMN_EINVAL, "smn_spr_loss_grad: empty");
   if (df > 0.0 && !(scale > 0.0)) return smn_fail(ctx, SMN_EINVAL, "smn_spr_loss_grad: scale must be > 0");

@@ -76,12 +76,12 @@ int aug_build(smn_ctx* ctx, const BuildSpec& spec, const Aug& g, const void* x, 
 int aug_finish(smn_ctx* ctx, int dtype, const Aug& g, const void* y, int64_t ldy, int64_t n_shift, double jitter_abs,
                double ridge_rel, void* mean, void* cov, int64_t ldcov, double* quad_h, double* logdet_h, int* info_h,
                bool td_identity = false) {
+  if (g.c > 48) return smn_fail(ctx, SMN_ENOTSUP, "more than 48 output columns");   // the mailbox holds 62 doubles
   SMN_TRY(set_aug_rows(ctx, dtype, g.a, g.lda, g.n_pad + g.t, g.n_total, y, g.n, g.c, ldy));
   // identity test rows: whole 128-row tiles of them may be skipped where they are structurally zero
   const int64_t id0 = td_identity ? g.n_pad : -1, id1 = td_identity ? g.n_pad + g.t / kTile * kTile : -1;
   SMN_TRY(cholesky_padded(ctx, dtype, g.a, g.n_total, g.n_pad, g.lda, n_shift, jitter_abs, ridge_rel, false, id0, id1));
   double* quad_dev = ctx->d_scal + 8;
-  if (g.c > 48) return smn_fail(ctx, SMN_ENOTSUP, "more than 48 output columns");
   SMN_TRY(extract_posterior(ctx, dtype, g.a, g.lda, g.n_pad, g.t, g.c, mean, cov, ldcov, quad_dev));
   double ld = 0.0;
   int info = 0;
@@ -101,6 +101,7 @@ int aug_finish(smn_ctx* ctx, int dtype, const Aug& g, const void* y, int64_t ldy
 extern "C" int smn_cholesky(smn_ctx* ctx, int dtype, void* a_d, int64_t n_total, int64_t n_factor, int64_t lda,
                             int64_t n_shift, double jitter_abs, double ridge_rel, int* info_h, double* logdet_h) {
   if (!ctx || !a_d) return SMN_EINVAL;
+  SMN_ENTER(ctx);
   if (dtype != SMN_F32 && dtype != SMN_F64) return smn_fail(ctx, SMN_EINVAL, "bad dtype");
   if (n_factor <= 0 || n_factor > n_total || lda < n_total || n_shift < 0 || n_shift > n_factor)
     return smn_fail(ctx, SMN_EINVAL, "smn_cholesky: bad sizes");
@@ -138,6 +139,7 @@ extern "C" int smn_cholesky(smn_ctx* ctx, int dtype, void* a_d, int64_t n_total,
 extern "C" int smn_trsm(smn_ctx* ctx, int dtype, const void* l_d, int64_t n, int64_t ldl, void* b_d, int64_t nrhs,
                         int64_t ldb, int trans) {
   if (!ctx || !l_d || !b_d) return SMN_EINVAL;
+  SMN_ENTER(ctx);
   if (dtype != SMN_F32 && dtype != SMN_F64) return smn_fail(ctx, SMN_EINVAL, "bad dtype");
   if (n <= 0 || nrhs <= 0) return smn_fail(ctx, SMN_EINVAL, "smn_trsm: empty");
   if (trans != 0 && trans != 1) return smn_fail(ctx, SMN_EINVAL, "smn_trsm: trans must be 0 or 1");
@@ -166,6 +168,7 @@ extern "C" int smn_trsm(smn_ctx* ctx, int dtype, const void* l_d, int64_t n, int
 extern "C" int smn_lml(smn_ctx* ctx, int dtype, void* k_d, int64_t n, int64_t ldk, const void* y_d, double eps_abs,
                        double df, double scale, double* logpdf_h, double* quad_h, double* logdet_h, int* info_h) {
   if (!ctx || !k_d || !y_d) return SMN_EINVAL;
+  SMN_ENTER(ctx);
   if (dtype != SMN_F32 && dtype != SMN_F64) return smn_fail(ctx, SMN_EINVAL, "bad dtype");
   if (n <= 0) return smn_fail(ctx, SMN_EINVAL, "smn_lml: empty");
   if (df > 0.0 && !(scale > 0.0)) return smn_fail(ctx, SMN_EINVAL, "smn_lml: scale must be > 0");
@@ -192,6 +195,7 @@ extern "C" int smn_lml_from_blocks(smn_ctx* ctx, int dtype, const void* stage_d,
                                    int64_t block_rows, const void* y_d, double eps_abs, double df, double scale,
                                    double* logpdf_h, double* quad_h, double* logdet_h, int* info_h) {
   if (!ctx || !stage_d || !y_d) return SMN_EINVAL;
+  SMN_ENTER(ctx);
   if (dtype != SMN_F32 && dtype != SMN_F64) return smn_fail(ctx, SMN_EINVAL, "bad dtype");
   if (n <= 0) return smn_fail(ctx, SMN_EINVAL, "smn_lml_from_blocks: empty");
   if (df > 0.0 && !(scale > 0.0)) return smn_fail(ctx, SMN_EINVAL, "smn_lml_from_blocks: scale must be > 0");
@@ -216,6 +220,7 @@ int predict_joint(smn_ctx* ctx, int dtype, void* kj_d, int64_t n, int64_t t, int
   if (!ctx || !kj_d || !y_d) return SMN_EINVAL;
   if (dtype != SMN_F32 && dtype != SMN_F64) return smn_fail(ctx, SMN_EINVAL, "bad dtype");
   if (n <= 0 || t < 0 || c <= 0) return smn_fail(ctx, SMN_EINVAL, "smn_predict: bad sizes");
+  if (c > 48) return smn_fail(ctx, SMN_ENOTSUP, "more than 48 output columns");
   Aug g;
   SMN_TRY(aug_alloc(ctx, dtype, n, t, c, &g));
   const char* kb = static_cast<const char*>(kj_d);
@@ -231,6 +236,8 @@ int predict_joint(smn_ctx* ctx, int dtype, void* kj_d, int64_t n, int64_t t, int
 extern "C" int smn_predict(smn_ctx* ctx, int dtype, void* kj_d, int64_t n, int64_t t, int64_t ldk, const void* y_d,
                            int64_t c, double ridge_rel, double ridge_abs, void* mean_d, void* cov_d, int64_t ldcov,
                            double* quad_h, double* logdet_h, int* info_h) {
+  if (!ctx) return SMN_EINVAL;
+  SMN_ENTER(ctx);
   return predict_joint(ctx, dtype, kj_d, n, t, ldk, y_d, c, ridge_rel, ridge_abs, mean_d, cov_d, ldcov, quad_h, logdet_h,
                        info_h, false);
 }
@@ -240,6 +247,7 @@ extern "C" int smn_spr_loss(smn_ctx* ctx, int dtype, int net, int act, int num_h
                             double eps_abs, double df, double scale, double* logpdf_h, double* quad_h, double* logdet_h,
                             int* info_h) {
   if (!ctx || !x_d || !y_d) return SMN_EINVAL;
+  SMN_ENTER(ctx);
   if (dtype != SMN_F32 && dtype != SMN_F64) return smn_fail(ctx, SMN_EINVAL, "bad dtype");
   if (n <= 0 || d <= 0) return smn_fail(ctx, SMN_EINVAL, "smn_spr_loss: empty");
   if (df > 0.0 && !(scale > 0.0)) return smn_fail(ctx, SMN_EINVAL, "smn_spr_loss: scale must be > 0");
@@ -262,8 +270,10 @@ extern "C" int smn_spr_predict(smn_ctx* ctx, int dtype, int net, int act, int nu
                                int64_t ldxt, int64_t d, const void* y_d, int64_t c, double ridge_rel, double ridge_abs,
                                void* mean_d, void* cov_d, int64_t ldcov, double* quad_h, double* logdet_h, int* info_h) {
   if (!ctx || !x_d || !y_d || (t > 0 && !xt_d)) return SMN_EINVAL;
+  SMN_ENTER(ctx);
   if (dtype != SMN_F32 && dtype != SMN_F64) return smn_fail(ctx, SMN_EINVAL, "bad dtype");
   if (n <= 0 || d <= 0 || t < 0 || c <= 0) return smn_fail(ctx, SMN_EINVAL, "smn_spr_predict: bad sizes");
+  if (c > 48) return smn_fail(ctx, SMN_ENOTSUP, "more than 48 output columns");
   Aug g;
   SMN_TRY(aug_alloc(ctx, dtype, n, t, c, &g));
   BuildSpec s{dtype, net, act, num_hiddens, w_std, b_std, last_w_std};

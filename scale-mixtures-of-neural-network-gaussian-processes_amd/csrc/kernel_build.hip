@@ -848,6 +848,7 @@ extern "C" int smn_kernel_mlp(smn_ctx* ctx, int dtype, int net, int act, int num
                               const void* x2_d, int64_t n2, int64_t ldx2, int64_t d, int get_mask, int fill,
                               void* nngp_d, void* ntk_d, int64_t ldk) {
   SMN_TRY(check_common(ctx, dtype, n1, x2_d ? n2 : 1, d));
+  SMN_ENTER(ctx);
   if (!(get_mask & (SMN_GET_NNGP | SMN_GET_NTK))) return smn_fail(ctx, SMN_EINVAL, "empty get mask");
   if (((get_mask & SMN_GET_NNGP) && !nngp_d) || ((get_mask & SMN_GET_NTK) && !ntk_d))
     return smn_fail(ctx, SMN_EINVAL, "requested output pointer is NULL");
@@ -860,6 +861,7 @@ extern "C" int smn_kernel_mlp_rows(smn_ctx* ctx, int dtype, int net, int act, in
                                    int64_t d, int64_t row_begin, int64_t row_end, int get_mask,
                                    void* nngp_rows_d, void* ntk_rows_d, int64_t ldk) {
   SMN_TRY(check_common(ctx, dtype, n, 1, d));
+  SMN_ENTER(ctx);
   if (row_begin < 0 || row_end > n || row_end <= row_begin)
     return smn_fail(ctx, SMN_EINVAL, "bad row range [%lld,%lld)", (long long)row_begin, (long long)row_end);
   BuildSpec s{dtype, net, act, num_hiddens, w_std, b_std, last_w_std};
@@ -872,6 +874,7 @@ extern "C" int smn_kernel_mlp_lower_rows(smn_ctx* ctx, int dtype, int net, int a
                                          int64_t d, int64_t row_begin, int64_t row_end, int get_mask,
                                          void* nngp_rows_d, void* ntk_rows_d, int64_t ldk) {
   SMN_TRY(check_common(ctx, dtype, n, 1, d));
+  SMN_ENTER(ctx);
   if (row_begin < 0 || row_end > n || row_end <= row_begin)
     return smn_fail(ctx, SMN_EINVAL, "bad row range [%lld,%lld)", (long long)row_begin, (long long)row_end);
   if (ldk < row_end) return smn_fail(ctx, SMN_EINVAL, "ldk %lld < row_end %lld", (long long)ldk, (long long)row_end);
@@ -885,6 +888,7 @@ extern "C" int smn_kernel_mlp_shard(smn_ctx* ctx, int dtype, int net, int act, i
                                     int64_t d, int nranks, int rank, int64_t block_rows, int get_mask,
                                     void* nngp_chunk_d, void* ntk_chunk_d) {
   SMN_TRY(check_common(ctx, dtype, n, 1, d));
+  SMN_ENTER(ctx);
   if (nranks <= 0 || rank < 0 || rank >= nranks || block_rows <= 0 || block_rows % kTile ||
       2 * (int64_t)nranks * block_rows < n)
     return smn_fail(ctx, SMN_EINVAL, "smn_kernel_mlp_shard: bad geometry (n=%lld ranks=%d rank=%d block_rows=%lld)",
@@ -922,6 +926,7 @@ extern "C" int smn_kernel_mlp_shard(smn_ctx* ctx, int dtype, int net, int act, i
 extern "C" int smn_gram(smn_ctx* ctx, int dtype, const void* x1_d, int64_t n1, int64_t ldx1, const void* x2_d,
                         int64_t n2, int64_t ldx2, int64_t d, void* k0_d, int64_t ldk, void* q1_d, void* q2_d) {
   SMN_TRY(check_common(ctx, dtype, n1, x2_d ? n2 : 1, d));
+  SMN_ENTER(ctx);
   BuildSpec s{dtype, NET_NONE, SMN_ACT_RELU, 0, 1.0, 0.0, 1.0};
   return build_public(ctx, s, x1_d, n1, ldx1, x2_d, n2, ldx2, d, SMN_GET_NNGP, SMN_FILL_FULL, 0, 0, k0_d, nullptr,
                       ldk, q1_d, q2_d);
@@ -932,6 +937,7 @@ extern "C" int smn_recursion(smn_ctx* ctx, int dtype, int net, int act, int num_
                              const void* q1_d, const void* q2_d, int symmetric, int get_mask, void* nngp_d,
                              void* ntk_d, int64_t ldk) {
   SMN_TRY(check_common(ctx, dtype, n1, n2, 1));
+  SMN_ENTER(ctx);
   BuildSpec s{dtype, net, act, num_hiddens, w_std, b_std, last_w_std};
   if (dtype == SMN_F64)
     return recursion_t<double>(ctx, s, k0_d, n1, n2, ldk0, q1_d, q2_d, symmetric, get_mask, nngp_d, ntk_d, ldk);

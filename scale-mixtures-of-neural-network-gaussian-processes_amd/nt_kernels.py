@@ -58,7 +58,7 @@ class KernelFn:
         return (self.net, self.act, self.num_hiddens, self.w_std, self.b_std, self.last_w_std)
 
     def __call__(self, x1, x2=None, get="nngp", fill="full"):
-        ctx = self.ctx or default_context()
+        ctx = self.ctx or (x1.ctx if isinstance(x1, DeviceArray) else default_context())
         names, mask = _parse_get(get)
         a = as_device(x1, ctx)
         if len(a.shape) != 2:
@@ -112,7 +112,7 @@ class CnnKernelFn:
     def __call__(self, x1, x2=None, get="nngp", fill="full"):
         if get != "nngp":
             raise NotImplementedError("conv kernel: only get='nngp' is on the hot path")
-        ctx = self.ctx or default_context()
+        ctx = self.ctx or (x1.ctx if isinstance(x1, DeviceArray) else default_context())
         a = as_device(x1, ctx)
         if len(a.shape) != 4:
             raise ValueError("conv kernel expects x of shape [N,H,W,C]")

@@ -27,7 +27,7 @@ class PredictResult(tuple):
 
 
 def gradient_descent_mse_ensemble(kernel_fn, x_train, y_train, diag_reg=0.0, diag_reg_absolute_scale=False):
-    ctx = getattr(kernel_fn, "ctx", None) or default_context()
+    ctx = getattr(kernel_fn, "ctx", None) or (x_train.ctx if isinstance(x_train, _lib.DeviceArray) else default_context())
     x = as_device(x_train, ctx)
     y = as_device(np.asarray(y_train).reshape(x.shape[0], -1) if not isinstance(y_train, _lib.DeviceArray) else y_train,
                   ctx, dtype=x.dtype)

@@ -81,7 +81,7 @@ class StudentTLikelihood(Likelihood):
         else:
             if getattr(cov_data, "dtype", None) == np.float32:
                 # 1e-6 jitter is below fp32 resolution of an O(1) kernel: factor this one in fp64
-                cov_data = as_device(np.asarray(cov_data, dtype=np.float64))
+                cov_data = as_device(np.asarray(cov_data, dtype=np.float64), getattr(cov_data, "ctx", None))
             quad, _, _ = factor_stats(y_data, (b / a) * cov_data + jitter(num_data))
         d = df + quad
         sigma = np.sqrt(np.diagonal(d / cond_df * b / a * np.asarray(cov, dtype=np.float64)))

@@ -23,5 +23,8 @@ for n, v in sorted(c.items(), key=lambda kv: -kv[1][1]): print("  main %-40s x%-
 gaps = [(main[i + 1][0] - main[i][1]) / 1e3 for i in range(len(main) - 1)]
 print("main: busy %.3f ms, gaps: median %.1f us, sum %.3f ms" % (sum(k[1] - k[0] for k in main) / 1e6, statistics.median(gaps), sum(gaps) / 1e3))
 # per super-panel (between far-update launches on main = update_kernel<float,1> with big grid?) print panel durations
-pan = [(k[1] - k[0]) / 1e3 for k in main if k[2].startswith("panel_kernel")]
-print("panel us: first 16", [round(p) for p in pan[:16]], "last 16", [round(p) for p in pan[-16:]])
+for nm in ("potrf_kernel", "trsm_kernel"):
+    pan = [(k[1] - k[0]) / 1e3 for k in main if k[2].startswith(nm)]
+    print(nm, "us: first 16", [round(p) for p in pan[:16]], "last 16", [round(p) for p in pan[-16:]])
+# chain spans: from the first potrf of a block to the last trsm before the next bulk launch
+

@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 from oracle import nngp_oracle as O
+from _tol import relerr  # norm-wise AND element-wise: tests/_tol.py
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "nngp_golden.npz")
 
@@ -74,12 +75,12 @@ def test_hip_kernels_match_golden(gold, dtype, tol):
         kfn = nt_kernels.get_mlp_kernel(c["L"], act=c["act"], w_std=c["w"], b_std=c["b"], last_w_std=c["lw"])
         got = kfn(x.astype(dtype), None, get=("nngp", "ntk"))
         ref = gold[name + "/k"]
-        assert np.max(np.abs(np.asarray(got.nngp) - ref)) < tol * np.max(np.abs(ref)), name
+        assert relerr(np.asarray(got.nngp), ref) < tol, name
         if name + "/t" in gold:
             rt = gold[name + "/t"]
-            assert np.max(np.abs(np.asarray(got.ntk) - rt)) < 5 * tol * np.max(np.abs(rt)), name
+            assert relerr(np.asarray(got.ntk), rt) < 5 * tol, name
         kc = np.asarray(kfn(x2.astype(dtype), x.astype(dtype), get="nngp"))
-        assert np.max(np.abs(kc - gold[name + "/kc"])) < tol * np.max(np.abs(gold[name + "/kc"])), name
+        assert relerr(kc, gold[name + "/kc"]) < tol, name
 
 
 @pytest.mark.gpu
@@ -104,8 +105,8 @@ def test_hip_cnn_matches_golden(gold):
     from smnngp import nt_kernels
     for act in ("relu", "erf"):
         k = np.asarray(nt_kernels.get_cnn_kernel(3, act=act, w_std=1.3, b_std=0.2, last_w_std=0.9)(gold["cnn/x"]))
-        assert np.max(np.abs(k - gold["cnn/k_" + act])) < 1e-9 * np.max(np.abs(gold["cnn/k_" + act]))
+        assert relerr(k, gold["cnn/k_" + act]) < 1e-9
         for bs in (1, 2):
             kr = np.asarray(nt_kernels.get_conv_resnet_kernel(bs, 10, act=act, w_std=1.2, b_std=0.3, last_w_std=0.9)(gold["resnet/x"]))
             ref = gold["resnet/k_%s_%d" % (act, bs)]
-            assert np.max(np.abs(kr - ref)) < 1e-9 * np.max(np.abs(ref))
+            assert relerr(kr, ref) < 1e-9

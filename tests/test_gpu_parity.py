@@ -25,9 +25,7 @@ def ctx(L):
     return L.default_context()
 
 
-def relerr(a, b):
-    a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
-    return np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300)
+from _tol import relerr, relerr_norm  # noqa: E402  norm-wise AND element-wise (|a-b| <= rtol |b| + rtol 1e-3 max|b|): tests/_tol.py
 
 
 # ----------------------------------------------------------------------------- kernel build
@@ -492,7 +490,7 @@ def test_cnn_kernel_feeds_the_same_inference_heads():
     mean, cov = predict.gradient_descent_mse_ensemble(kfn, x, y, diag_reg=1e-3)(x_test=xt)
     kw = dict(num_hiddens=2, act="relu", w_std=1.2, b_std=0.1, last_w_std=1.0)
     rm, rc = O.predict(O.cnn_kernel(x, None, **kw), O.cnn_kernel(xt, x, **kw), O.cnn_kernel(xt, None, **kw), y, 1e-3)
-    assert relerr(np.asarray(mean), rm) < 1e-7 and relerr(np.asarray(cov), rc) < 1e-7
+    assert relerr_norm(np.asarray(mean), rm) < 1e-7 and relerr_norm(np.asarray(cov), rc) < 1e-7
 
 
 # ----------------------------------------------------------------------------- factorisation
@@ -516,12 +514,12 @@ def test_cholesky_and_schur(L, ctx, dtype, n, m):
     tol = 1e-9 if dtype == np.float64 else 5e-3
     assert info.value == 0
     assert abs(logdet.value - 2 * np.log(np.diag(l)).sum()) < tol * max(1.0, abs(logdet.value))
-    assert relerr(np.tril(got[:n, :n]), l) < tol
+    assert relerr_norm(np.tril(got[:n, :n]), l) < tol
     if m:
         w = sla.solve_triangular(l, a[:n, n:], lower=True).T        # B L^-T
-        assert relerr(got[n:, :n], w) < tol
+        assert relerr_norm(got[n:, :n], w) < tol
         s = a[n:, n:] - w @ w.T
-        assert relerr(np.tril(got[n:, n:]), np.tril(s)) < tol
+        assert relerr_norm(np.tril(got[n:, n:]), np.tril(s)) < tol
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
@@ -565,28 +563,29 @@ def test_cholesky_more_workgroups_than_cus_and_lookahead(L, ctx, dtype, n, m):
     assert info.value == 0
     assert abs(logdet.value - 2 * np.log(np.diag(l)).sum()) < tol * abs(logdet.value)
     got = ad.numpy().astype(np.float64)
-    assert relerr(np.tril(got[:n, :n]), l) < tol
+    assert relerr_norm(np.tril(got[:n, :n]), l) < tol
     if m:
         w = sla.solve_triangular(l, a[:n, n:], lower=True).T
-        assert relerr(got[n:, :n], w) < tol
-        assert relerr(np.tril(got[n:, n:]), np.tril(a[n:, n:] - w @ w.T)) < tol
+        assert relerr_norm(got[n:, :n], w) < tol
+        assert relerr_norm(np.tril(got[n:, n:]), np.tril(a[n:, n:] - w @ w.T)) < tol
 
 
 @pytest.mark.parametrize("env", [
-    {"SMN_CHAIN_CUS": "0"},                                    # two-level, serial
+    {"SMN_CHAIN_CUS": "0"},                                    # no look-ahead: one stream, serial
     {"SMN_CHAIN_CUS": "64"},                                   # masked look-ahead, other reservation
-    {"SMN_SUPER": "0", "SMN_CHAIN_CUS": "0"},                  # one level
-    {"SMN_LOOKAHEAD": "1"},                                    # one-level look-ahead, updates on the masked stream
-    {"SMN_LOOKAHEAD": "1", "SMN_CHAIN_CUS": "0"},              # one-level look-ahead on plain streams
+    {"SMN_CHAIN_CUS": "8"},
+    {"SMN_SUPER": "256"},                                      # a super-panel = one outer panel: no near updates
+    {"SMN_SUPER": "512"},
+    {"SMN_SUPER": "2048"},
+    {"SMN_SUPER": "512", "SMN_CHAIN_CUS": "0"},
     {"SMN_PERSISTENT": "0"},
     {"SMN_PERSIST_MAXK": "1024"},
-    {"SMN_SUPER": "2048"},
     {"SMN_XCD_MAP": "1"},
     {"SMN_HALF_TILES": "0"},                                   # no 64-row tiles for the small launches
     {"SMN_HALF_TILES": "100000"},                              # 64-row tiles everywhere
-    {"SMN_F0_SPLIT": "1"},                                     # third level of look-ahead: F0 in two, on two streams
     {"SMN_QUARTER_TILES": "0"},                                # no 64x64 tiles for the smallest launches
     {"SMN_QUARTER_TILES": "100000"},                           # 64x64 tiles everywhere
+    {"SMN_PANEL_SMALL": "0"},                                  # 128-row panel workgroups throughout
 ])
 def test_cholesky_schedule_variants_agree(L, env):
     """Every schedule the environment switches select factors the same matrix to the same result (the default
@@ -618,13 +617,13 @@ def test_cholesky_schedule_variants_agree(L, env):
     # different K groupings round differently in fp32: agreement to fp32 accumulation accuracy, not bit for bit
     assert i0 == 0 and i1 == 0 and abs(ld1 - ld0) < 1e-5 * abs(ld0)
     il = np.tril_indices(n + m)
-    assert relerr(f1[il], f0[il]) < 1e-4
+    assert relerr_norm(f1[il], f0[il]) < 1e-4
 
 
 @pytest.mark.parametrize("dtype,n,m", [(np.float32, 9216, 128), (np.float64, 8192, 0)])
 def test_cholesky_lookahead_is_bitwise_reproducible(L, ctx, dtype, n, m):
-    """The look-ahead runs the far updates on a second stream beside the panel chain.  A missing dependency would
-    show as run-to-run differences: eight factorizations of the same matrix must agree bit for bit."""
+    """The look-ahead runs the block updates on a second stream beside the next block's panel chain.  A missing
+    dependency would show as run-to-run differences: eight factorizations of the same matrix must agree bit for bit."""
     rng = np.random.default_rng(8)
     g = rng.standard_normal((n + m, 80)).astype(dtype)
     a = (g @ g.T / 80 + np.diag(rng.uniform(1.0, 2.0, n + m))).astype(dtype)
@@ -666,12 +665,12 @@ def test_trsm_lower(L, ctx, dtype):
     ld = ctx.to_device(l.astype(dtype)); bd = ctx.to_device(b.astype(dtype))
     ctx.call("smn_trsm", L.dtype_code(dtype), ld.ptr, n, n, bd.ptr, r, r, 0)
     ref = sla.solve_triangular(l, b, lower=True)
-    assert relerr(bd.numpy(), ref) < (1e-9 if dtype == np.float64 else 2e-3)
+    assert relerr_norm(bd.numpy(), ref) < (1e-9 if dtype == np.float64 else 2e-3)
     # trans = 1: L^T X = B; together the two solves are cho_solve (K^-1 B)
     ctx.call("smn_trsm", L.dtype_code(dtype), ld.ptr, n, n, bd.ptr, r, r, 1)
     ref2 = sla.solve_triangular(l, ref, lower=True, trans="T")
-    assert relerr(bd.numpy(), ref2) < (1e-8 if dtype == np.float64 else 5e-3)
-    assert relerr(bd.numpy(), sla.cho_solve((l, True), b)) < (1e-8 if dtype == np.float64 else 5e-3)
+    assert relerr_norm(bd.numpy(), ref2) < (1e-8 if dtype == np.float64 else 5e-3)
+    assert relerr_norm(bd.numpy(), sla.cho_solve((l, True), b)) < (1e-8 if dtype == np.float64 else 5e-3)
 
 
 # ----------------------------------------------------------------------------- heads
@@ -714,14 +713,14 @@ def test_predict_joint_and_fused(L, ctx, dtype, n, t, c):
     mean, cov = np.asarray(res[0]), np.asarray(res[1])
     tol = 1e-7 if dtype == np.float64 else 1e-2
     assert mean.shape == (t, c) and cov.shape == (t, t)
-    assert relerr(mean, rmean) < tol and relerr(cov, rcov) < tol
+    assert relerr_norm(mean, rmean) < tol and relerr_norm(cov, rcov) < tol
     kt = kdd + eps * np.trace(kdd) / n * np.eye(n)
     rquad = [float(y[:, k].astype(np.float64) @ np.linalg.solve(kt, y[:, k].astype(np.float64))) for k in range(c)]
     assert np.allclose(res.quad, rquad, rtol=tol)
     # generic kernel_fn path (joint kernel handed to smn_predict)
     pf2 = predict.gradient_descent_mse_ensemble(lambda a, b, g: kfn(a, b, g), x, y, diag_reg=eps)
     m2, c2 = pf2(x_test=xt)
-    assert relerr(np.asarray(m2), rmean) < tol and relerr(np.asarray(c2), rcov) < tol
+    assert relerr_norm(np.asarray(m2), rmean) < tol and relerr_norm(np.asarray(c2), rcov) < tol
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
@@ -739,9 +738,9 @@ def test_predict_ntk_posterior(dtype, act):
     kj, tj = O.mlp_kernel(xa, None, 2, act, 1.3, 0.2, 1.1, ("nngp", "ntk"))
     rmean, rcov = O.predict_ntk(kj[:n, :n], kj[n:, :n], kj[n:, n:], tj[:n, :n], tj[n:, :n], y, diag_reg=eps)
     tol = 1e-7 if dtype == np.float64 else 1e-2
-    assert relerr(mean, rmean) < tol and relerr(cov, rcov) < tol
+    assert relerr_norm(mean, rmean) < tol and relerr_norm(cov, rcov) < tol
     only_mean = pf(x_test=xt.astype(dtype), get="ntk", compute_cov=False)
-    assert relerr(only_mean, rmean) < tol
+    assert relerr_norm(only_mean, rmean) < tol
     with pytest.raises(NotImplementedError):
         pf(x_test=xt.astype(dtype), get="bogus")
 
@@ -1028,3 +1027,86 @@ def test_analytic_train_step_descends_and_agrees_with_fd_step():
     assert losses[-1] < losses[0]
     with pytest.raises(ValueError):
         train.build_train_step(ma, method="bogus")
+
+
+# ----------------------------------------------------------------------------- host-side contracts (round-2 advice)
+def test_context_driven_from_a_thread_that_did_not_create_it(L, ctx):
+    """The current HIP device belongs to the calling THREAD: every entry point makes the context's device current
+    itself (SMN_ENTER), so a context made in the main thread works from a worker (sweeps.py does exactly this)."""
+    import threading
+    rng = np.random.default_rng(70)
+    x = rng.standard_normal((200, 12)); y = rng.standard_normal(200)
+    want = O.spr_loss(x, y, num_hiddens=2, act="relu", w_std=1.2, b_std=0.3, last_w_std=1.0, eps=1e-3, method="gp")
+    c2 = L.Context(ctx.device)              # created here ...
+    got, err = [], []
+
+    def work():                             # ... driven there (allocations, attributes, launches, events)
+        try:
+            xd = c2.to_device(x); yd = c2.to_device(y)
+            lp, quad, logdet, info = C.c_double(), C.c_double(), C.c_double(), C.c_int()
+            c2.call("smn_profile_enable", 1)
+            c2.call("smn_spr_loss", L.F64, L.NET_MLP, L.ACT["relu"], 2, 1.2, 0.3, 1.0, xd.ptr, 200, 12, 12, yd.ptr, 1e-3,
+                    0.0, 1.0, C.byref(lp), C.byref(quad), C.byref(logdet), C.byref(info))
+            c2.call("smn_profile_enable", 0)
+            got.append(-lp.value / 200)
+            del xd, yd
+        except Exception as e:              # noqa: BLE001
+            err.append(e)
+    t = threading.Thread(target=work); t.start(); t.join()
+    assert not err, err
+    assert abs(got[0] - want) < 1e-9 * max(1.0, abs(want))
+    c2.close()
+
+
+def test_two_contexts_on_two_devices_in_one_thread(L):
+    n = C.c_int(0)
+    L._lib.smn_device_count(C.byref(n))
+    if n.value < 2:
+        pytest.skip("one visible device")
+    rng = np.random.default_rng(71)
+    x = rng.standard_normal((150, 8)); y = rng.standard_normal(150)
+    want = O.spr_loss(x, y, num_hiddens=1, act="erf", w_std=1.0, b_std=0.2, last_w_std=1.0, eps=1e-3, method="gp")
+    ctxs = [L.Context(0), L.Context(1)]
+    for c in (ctxs[1], ctxs[0], ctxs[1]):   # alternate: the guard must switch every call
+        xd = c.to_device(x); yd = c.to_device(y)
+        lp, quad, logdet, info = C.c_double(), C.c_double(), C.c_double(), C.c_int()
+        c.call("smn_spr_loss", L.F64, L.NET_MLP, L.ACT["erf"], 1, 1.0, 0.2, 1.0, xd.ptr, 150, 8, 8, yd.ptr, 1e-3, 0.0, 1.0,
+               C.byref(lp), C.byref(quad), C.byref(logdet), C.byref(info))
+        assert abs(-lp.value / 150 - want) < 1e-9 * max(1.0, abs(want))
+        del xd, yd
+
+
+def test_as_device_checks_context_dtype_and_views(L, ctx):
+    from smnngp import nt_kernels, predict
+    rng = np.random.default_rng(72)
+    a = ctx.to_device(rng.standard_normal((6, 6)))
+    assert L.as_device(a, ctx) is a
+    v = 2.0 * a + L.ScaledIdentity(6, 0.5)                 # a lazy view: the raw pointer still holds A
+    m = L.as_device(v, ctx)
+    assert m is not v and m.scale == 1.0 and m.shift == 0.0
+    assert np.allclose(m.raw_numpy(), 2.0 * a.raw_numpy() + 0.5 * np.eye(6))
+    f = L.as_device(a, ctx, dtype=np.float32)              # converted, not reinterpreted
+    assert f.dtype == np.float32 and np.allclose(f.raw_numpy(), a.raw_numpy().astype(np.float32))
+    other = L.Context(ctx.device)
+    with pytest.raises(ValueError):
+        L.as_device(a, other)
+    # an f64 DeviceArray x_test with f32 training data is converted (it used to be read as f32)
+    x = rng.standard_normal((40, 5)).astype(np.float32); y = rng.standard_normal(40).astype(np.float32)
+    xt64 = rng.standard_normal((7, 5))
+    kfn = nt_kernels.get_mlp_kernel(2, act="relu", w_std=1.1, b_std=0.2)
+    pf = predict.gradient_descent_mse_ensemble(kfn, x, y[:, None], diag_reg=1e-2)
+    m_dev, c_dev = pf(x_test=ctx.to_device(xt64), get="nngp", compute_cov=True)
+    m_np, c_np = pf(x_test=xt64.astype(np.float32), get="nngp", compute_cov=True)
+    assert np.allclose(np.asarray(m_dev), np.asarray(m_np), rtol=1e-5, atol=1e-6)
+    assert np.allclose(np.asarray(c_dev), np.asarray(c_np), rtol=1e-5, atol=1e-6)
+    other.close()
+
+
+def test_too_many_output_columns_is_rejected_before_anything_runs(L, ctx):
+    rng = np.random.default_rng(73)
+    x = ctx.to_device(rng.standard_normal((64, 4))); y = ctx.to_device(rng.standard_normal((64, 49)))
+    mean = ctx.empty((1, 49), np.float64)
+    with pytest.raises(L.SmnError) as e:
+        ctx.call("smn_spr_predict", L.F64, L.NET_MLP, L.ACT["relu"], 1, 1.0, 0.1, 1.0, x.ptr, 64, 4, x.ptr, 1, 4, 4, y.ptr, 49,
+                 1e-3, 0.0, mean.ptr, None, 1, None, None, None)
+    assert e.value.code == L.ENOTSUP

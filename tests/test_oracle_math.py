@@ -173,6 +173,80 @@ def test_dense_resnet_kernel_basic():
 
 
 @pytest.mark.parametrize("act", ["relu", "erf"])
+def test_dense_resnet_nngp_and_ntk_vs_finite_width_network(act):
+    """dense_resnet_kernel (experiments/nt_kernels.py:83-103: Dense; L x {FanOut; (act; Dense) + Identity; FanInSum};
+    act; Dense(last_w, b=0)) against an empirical width-2048 network in the NTK parameterisation
+    z = w/sqrt(n_in) W h + b beta (32 draws): NNGP = E[f f'] over 2048 read-out heads, NTK = <df/dtheta, df'/dtheta>
+    of one head.  Monte-Carlo error at this width / draw count is ~1-2 %; asserted at 4 %, element-wise."""
+    torch = pytest.importorskip("torch")
+    torch.manual_seed(2)
+    rng = np.random.default_rng(11)
+    n, d, L, width, heads, draws = 4, 6, 2, 2048, 2048, 32
+    w_std, b_std, lw = 1.1, 0.4, 0.8
+    x = torch.tensor(rng.standard_normal((n, d)), dtype=torch.float64)
+    phi = torch.relu if act == "relu" else torch.erf
+    nngp = np.zeros((n, n)); ntk = np.zeros((n, n))
+    for _ in range(draws):
+        params = [torch.randn(d, width, dtype=torch.float64, requires_grad=True),
+                  torch.randn(width, dtype=torch.float64, requires_grad=True)]
+        for _l in range(L):
+            params += [torch.randn(width, width, dtype=torch.float64, requires_grad=True),
+                       torch.randn(width, dtype=torch.float64, requires_grad=True)]
+        params += [torch.randn(width, heads, dtype=torch.float64, requires_grad=True)]
+        h = w_std / np.sqrt(d) * x @ params[0] + b_std * params[1]
+        for l in range(L):                                   # ResBlock: Dense(act(h)) + h
+            h = w_std / np.sqrt(width) * phi(h) @ params[2 + 2 * l] + b_std * params[3 + 2 * l] + h
+        out = lw / np.sqrt(width) * phi(h) @ params[-1]      # [n, heads]
+        nngp += (out @ out.T).detach().numpy() / heads / draws
+        g = []
+        for i in range(n):
+            gi = torch.autograd.grad(out[i, 0], params, retain_graph=True)
+            g.append(torch.cat([t.reshape(-1) for t in gi]))
+        g = torch.stack(g)
+        ntk += (g @ g.T).numpy() / draws
+    k, t = O.dense_resnet_kernel(x.numpy(), None, L, act, w_std, b_std, lw, ("nngp", "ntk"))
+    assert np.max(np.abs(nngp - k) / np.abs(k)) < 0.04, (nngp, k)
+    assert np.max(np.abs(ntk - t) / np.abs(t)) < 0.04, (ntk, t)
+    # cross form is the off-diagonal block of the joint kernel
+    kc, tc = O.dense_resnet_kernel(x.numpy()[:2], x.numpy()[1:], L, act, w_std, b_std, lw, ("nngp", "ntk"))
+    assert np.allclose(kc, k[:2, 1:], rtol=1e-9, atol=1e-12) and np.allclose(tc, t[:2, 1:], rtol=1e-6, atol=1e-9)
+
+
+@pytest.mark.parametrize("act", ["relu", "erf"])
+def test_cnn_kernel_vs_finite_width_network(act):
+    """cnn_kernel (experiments/nt_kernels.py:34-45: L x [Conv 3x3 stride 1 SAME; act]; Flatten; Dense(last_w)) against an
+    empirical 512-channel CNN in the NTK parameterisation (weights w/sqrt(9 c_in), ZERO padding so the divisor stays 9 at
+    the border, bias b beta per channel), flattened over (h, w, channel) into 512 read-out heads scaled
+    last_w/sqrt(H W ch): E[f f'] over 48 draws.  This is the check of the three conventions the oracle takes from NT's
+    documentation: SAME zero padding, the /9 divisor and Flatten = mean over pixels.  MC error 1-2 % (2.1 % worst entry at 96 draws, both activations); asserted 5 %, element-wise."""
+    torch = pytest.importorskip("torch")
+    F = torch.nn.functional
+    torch.manual_seed(3)
+    rng = np.random.default_rng(12)
+    n, hw, cin, ch, heads, draws, L = 3, 6, 3, 512, 512, 48, 2
+    w_std, b_std, lw = 1.3, 0.3, 0.9
+    xh = rng.standard_normal((n, hw, hw, cin))
+    x = torch.tensor(np.transpose(xh, (0, 3, 1, 2)))                    # NCHW
+    phi = torch.relu if act == "relu" else torch.erf
+    emp = np.zeros((n, n))
+    for _ in range(draws):
+        h = x
+        for _l in range(L):
+            c_in = h.shape[1]
+            wgt = torch.randn(ch, c_in, 3, 3, dtype=torch.float64)
+            bias = torch.randn(ch, dtype=torch.float64)
+            h = phi(F.conv2d(h, w_std / np.sqrt(9 * c_in) * wgt, b_std * bias, stride=1, padding=1))
+        flat = h.reshape(n, -1)
+        out = lw / np.sqrt(flat.shape[1]) * flat @ torch.randn(flat.shape[1], heads, dtype=torch.float64)
+        emp += (out @ out.T).numpy() / heads / draws
+    k = O.cnn_kernel(xh, None, L, act, w_std, b_std, lw)
+    assert np.max(np.abs(emp - k) / np.abs(k)) < 0.05, (emp, k)
+    # a network WITHOUT the border convention (divisor = number of taps inside the image) must NOT match: the test can tell
+    k_wrong = O.cnn_kernel(np.pad(xh, ((0, 0), (1, 1), (1, 1), (0, 0)), mode="edge"), None, L, act, w_std, b_std, lw)
+    assert np.max(np.abs(emp - k_wrong) / np.abs(k)) > 0.05
+
+
+@pytest.mark.parametrize("act", ["relu", "erf"])
 def test_conv_resnet_kernel_vs_finite_width_network(act):
     """conv_resnet_kernel (nt_kernels.py:48-80) against an empirical WideResnet of 192 channels (NTK
     parameterisation, 3x3 convolutions with stax's SAME padding, strides 1/2/2/2, Conv shortcut in the first block of
