@@ -2,12 +2,19 @@
 """bench.py — the hot path of BASELINE.json on MI355X: NNGP kernel build + jittered Cholesky (+ LML heads).
 
 One "step" = one SPR.loss evaluation (spax/models.py:93-98) on synthetic inputs already resident in HBM:
-fused Gram + 4-layer ReLU recursion -> K + eps I -> blocked Cholesky with y carried -> log-marginal
-likelihood.  Workload at N=1: BASELINE.json configs[3] shape on one GPU (N=16384, d=3072, L=4, fp32).
-With --gpus P > 1 (launched by torch.distributed.run, one rank per GPU): the kernel build is row-sharded
-over the ranks (paired lower-block layout, sharding.py), assembled with ONE RCCL all-gather, and every rank
-factors the assembled kernel
-(strong scaling: total work fixed).
+fused Gram + layer recursion -> K + eps I -> blocked Cholesky with y carried -> log-marginal likelihood.
+
+    python bench.py                         the metric's configuration on one GPU: N=16384 d=3072 L=4 ReLU fp32 (C4)
+    python bench.py --config c2|c5|c3       BASELINE.json's other configurations (shapes; c3 = conv-NNGP + Student-t, fp64)
+    python bench.py --gpus P                P ranks, one per GPU: the parent starts P fresh child processes BEFORE anything
+                                            touches a GPU (RANK / LOCAL_RANK / WORLD_SIZE in their environment); rank 0
+                                            hands the 128-byte RCCL id to the others through a file.  No torch, no launcher.
+    python -m torch.distributed.run --nproc-per-node P ... bench.py --gpus P    the same workers under an external launcher
+
+With P > 1 the kernel build is row-sharded over the ranks (paired lower-block layout, sharding.py) and the exchange is
+pipelined behind it: every rank's chunk goes out in pieces, each piece all-gathered (RCCL) and scattered into the
+factorisation workspace on a communication stream while the next piece is being built; every rank then factors the
+assembled kernel (strong scaling: total work fixed).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
 """
@@ -15,7 +22,9 @@ import argparse
 import ctypes as C
 import json
 import os
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -24,9 +33,16 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
-PEAK_F64_MFMA_TFLOPS = 78.6    # datasheet (not in the local guide)
+PEAK_F64_MFMA_TFLOPS = 78.6    # datasheet; the v_mfma_f64_16x16x4_f64 microbench: profiles/r02_mfma_f64_peak.txt
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s achievable)
 TILE = 128
+
+CONFIGS = {   # BASELINE.json `configs` (shapes); c4 is the one the metric is quoted on
+    "c4": dict(n=16384, d=3072, layers=4, act="relu", dtype="f32"),
+    "c2": dict(n=4096, d=512, layers=3, act="relu", dtype="f32"),
+    "c5": dict(n=32768, d=1024, layers=6, act="erf", dtype="f32"),
+    "c3": dict(n=10000, d=3072, layers=4, act="relu", dtype="f64"),      # 32x32x3 images, conv-NNGP, Student-t
+}
 
 
 def parse():
@@ -34,31 +50,112 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=20)
     p.add_argument("--warmup", type=int, default=3)
-    p.add_argument("--n", type=int, default=16384)
-    p.add_argument("--d", type=int, default=3072)
-    p.add_argument("--layers", type=int, default=4)
-    p.add_argument("--act", default="relu")
-    p.add_argument("--dtype", default="f32", choices=["f32", "f64"])
+    p.add_argument("--config", default="c4", choices=sorted(CONFIGS))
+    p.add_argument("--n", type=int, default=None)
+    p.add_argument("--d", type=int, default=None)
+    p.add_argument("--layers", type=int, default=None)
+    p.add_argument("--act", default=None)
+    p.add_argument("--dtype", default=None, choices=["f32", "f64"])
     p.add_argument("--eps", type=float, default=None)
+    p.add_argument("--parts", type=int, default=0, help="pieces of the pipelined exchange (0: sharding.default_parts)")
     p.add_argument("--cpu-sample-n", type=int, default=0, help="0: the benched N")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-recursion-probe", action="store_true")
     p.add_argument("--no-exclusive-probe", action="store_true", help="skip the look-ahead-off pass that fills frac_exclusive")
     p.add_argument("--sharded-path", action="store_true",
-                   help="run the N>1 step (row shard + all-gather + LML) even with one rank (rehearsal on one GPU)")
-    return p.parse_args()
+                   help="run the P>1 step (sharded build + pipelined exchange + LML) even with one rank (rehearsal on one GPU)")
+    p.add_argument("--rendezvous-file", default=None, help=argparse.SUPPRESS)
+    a = p.parse_args()
+    for k, v in CONFIGS[a.config].items():
+        if getattr(a, k) is None:
+            setattr(a, k, v)
+    return a
 
 
-def pmc_traffic(args, sharded):
-    """Measured HBM-side bytes per launch of the dominant kernel (persistent launches only), from the committed
-    rocprofv3 PMC pass; only valid for the default workload it was taken on."""
-    if sharded or (args.n, args.d, args.layers, args.act, args.dtype) != (16384, 3072, 4, "relu", "f32"):
-        return None
+# ----------------------------------------------------------------------------- launcher (no GPU call in this process)
+def launch_ranks(args):
+    """`python bench.py --gpus P` without a launcher: P fresh children, one per GPU.  This process never touches a GPU
+    (a GPU-initialised process must not be re-executed), it only waits; the children rendezvous through a file."""
+    tmp = tempfile.mkdtemp(prefix="smnngp_bench_")
+    rdv = os.path.join(tmp, "rccl_id")
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus))
+        cmd = [sys.executable, os.path.abspath(sys.argv[0])] + sys.argv[1:] + ["--rendezvous-file", rdv]   # the script as invoked
+        procs.append(subprocess.Popen(cmd, env=env, stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
     try:
-        with open(os.path.join(ROOT, "profiles", "r01f_pmc_traffic.json")) as f:
-            return json.load(f)["traffic_bytes_per_launch"]
-    except Exception:
+        for f in os.listdir(tmp):
+            os.unlink(os.path.join(tmp, f))
+        os.rmdir(tmp)
+    except OSError:
+        pass
+    sys.exit(rc)
+
+
+def exchange_rccl_id(L, path, rank, timeout_s=120.0):
+    """Rank 0 creates the 128-byte RCCL id and publishes it with an atomic rename; the others poll for the file."""
+    uid = C.create_string_buffer(128)
+    if rank == 0:
+        assert L._lib.smn_comm_unique_id(uid) == 0, "RCCL unavailable"
+        with open(path + ".tmp", "wb") as f:
+            f.write(uid.raw)
+        os.replace(path + ".tmp", path)
+        return uid
+    t0 = time.time()
+    while True:
+        try:
+            with open(path, "rb") as f:
+                raw = f.read()
+            if len(raw) == 128:
+                return C.create_string_buffer(raw, 128)
+        except FileNotFoundError:
+            pass
+        if time.time() - t0 > timeout_s:
+            raise RuntimeError("rank %d: no RCCL id at %s after %.0f s" % (rank, path, timeout_s))
+        time.sleep(0.02)
+
+
+class RankSync:
+    """Host-side barrier and max-over-ranks through the one collective the library has (an RCCL all-gather of one
+    double per rank on the context's stream): no torch, no MPI."""
+
+    def __init__(self, ctx, world, rank):
+        self.ctx, self.world, self.rank = ctx, world, rank
+        self.buf = ctx.empty((max(world, 1),), np.float64) if world > 1 else None
+
+    def gather(self, value):
+        if self.world == 1:
+            return [value]
+        mine = np.array([value], np.float64)
+        slot = C.c_void_p(self.buf.ptr.value + 8 * self.rank)
+        self.ctx.call("smn_memcpy_h2d", slot, mine.ctypes.data_as(C.c_void_p), 8)
+        self.ctx.call("smn_allgather", 1, slot, self.buf.ptr, 1)   # in place, dtype code 1 = f64
+        return list(self.buf.numpy())
+
+    def barrier(self):
+        self.ctx.synchronize()
+        self.gather(0.0)
+
+    def max(self, value):
+        return max(self.gather(value))
+
+
+# ----------------------------------------------------------------------------- helpers
+def pmc_traffic(args, sharded):
+    """Measured L2-fabric-side bytes per launch of the dominant kernel, from the committed rocprofv3 PMC pass of this exact
+    workload (bench.py cannot run the profiler on itself); None for any other workload."""
+    if sharded or args.config != "c4" or (args.n, args.d, args.layers, args.act, args.dtype) != (16384, 3072, 4, "relu", "f32"):
         return None
+    for name in ("r02_pmc_traffic.json", "r01f_pmc_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                return json.load(f)["traffic_bytes_per_launch"]
+        except Exception:
+            continue
+    return None
 
 
 def cpu_baseline(args, np_dtype, eps, gpu_logpdf=None):
@@ -66,7 +163,7 @@ def cpu_baseline(args, np_dtype, eps, gpu_logpdf=None):
     (--cpu-sample-n), on this box's host cores.  Also the checker of the headline number: the oracle's log-pdf and
     its relative difference to the GPU's (same inputs, same dtype) go into the line when N is the benched N."""
     from oracle import host_parallel as HP       # test infrastructure: imported by this leg only
-    ns = min(args.cpu_sample_n or args.n, args.n)
+    ns = min(args.cpu_sample_n or min(args.n, 16384), args.n)     # bounded: LAPACK at N = 32768 alone is minutes of host time
     rng = np.random.default_rng(0)
     x = rng.standard_normal((args.n, args.d)).astype(np_dtype)[:ns]     # the GPU's inputs (same seed, same draw order)
     y = rng.standard_normal(args.n).astype(np_dtype)[:ns]
@@ -109,23 +206,91 @@ class _JsonOut:
         os.write(self.fd, (line + "\n").encode())
 
 
+CATS = ["prep", "build", "recursion", "panel", "strip", "trail", "misc", "comm", "exposed"]
+
+
+def read_profile(ctx, per_steps):
+    prof = {}
+    for cat, name in enumerate(CATS):
+        ms, cnt = C.c_double(), C.c_int()
+        ctx.call("smn_profile_read", cat, C.byref(ms), C.byref(cnt))
+        prof[name] = (ms.value / per_steps, cnt.value // per_steps)
+    return prof
+
+
+# ----------------------------------------------------------------------------- C3: conv-NNGP + Student-t, fp64
+def bench_conv(args, out_fd, L, ctx, sync, rank, world):
+    """BASELINE configs[2]: 4-layer conv-NNGP kernel of N CIFAR-shaped images (32x32x3) + Student-t (inverse-gamma scale
+    mixture, alpha = beta = 2) log-marginal likelihood, fp64, one GPU.  SURVEY 8(d): VALU-bound, reported as
+    pair-pixel-layers per second with the VALU-busy share of the committed PMC pass."""
+    n, nl = args.n, args.layers
+    h = w = 32; c = 3
+    rng = np.random.default_rng(0)
+    xh = rng.standard_normal((n, h, w, c))
+    xh /= np.sqrt((xh ** 2).mean(axis=(1, 2, 3), keepdims=True))
+    yh = (rng.integers(0, 10, n) == 3).astype(np.float64) - 0.1
+    x = ctx.to_device(xh); y = ctx.to_device(yh)
+    k = ctx.empty((n, n), np.float64)
+    eps = args.eps if args.eps is not None else 1e-4
+    lp, quad, logdet, info = C.c_double(), C.c_double(), C.c_double(), C.c_int()
+    tb = [0.0]
+
+    def step():
+        t0 = time.perf_counter()
+        ctx.call("smn_kernel_cnn", L.F64, L.ACT[args.act], nl, 1.3, 0.2, 1.0, x.ptr, n, None, 0, h, w, c, L.FILL_LOWER, k.ptr, n)
+        ctx.synchronize()
+        tb[0] += time.perf_counter() - t0
+        ctx.call("smn_lml", L.F64, k.ptr, n, n, y.ptr, eps, 4.0, 1.0, C.byref(lp), C.byref(quad), C.byref(logdet), C.byref(info))
+
+    for _ in range(args.warmup):
+        step()
+    sync.barrier()
+    tb[0] = 0.0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync.barrier()
+    dt = time.perf_counter() - t0
+    ms_per_step = dt / args.steps * 1e3
+    build_ms = tb[0] / args.steps * 1e3
+    ppl = n * (n + 1) / 2.0 * h * w * nl                       # pair-pixel-layers of the lower triangle (what is computed)
+    valu = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r02_pmc_cnn.json")) as f:
+            valu = json.load(f)
+    except Exception:
+        pass
+    out = {
+        "metric": "conv-NNGP kernel build + Student-t LML wallclock at N=%d 32x32x3 images, %d-layer %s, fp64" % (n, nl, args.act),
+        "value": ppl / (build_ms * 1e-3), "unit": "pair-pixel-layers/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "C3: get_cnn_kernel(%d, %s) on %d images 32x32x3 (lower triangle) + smn_lml Student-t df=4" % (nl, args.act, n),
+                   "N": n, "layers": nl, "act": args.act, "w_std": 1.3, "b_std": 0.2, "eps_abs": eps, "parallelism": "single GPU"},
+        "phases_ms": {"kernel_build": round(build_ms, 3), "cholesky_lml": round(ms_per_step - build_ms, 3)},
+        "result": {"logpdf": lp.value, "logdet": logdet.value, "info": info.value},
+        "roofline": {"kernel": "conv_pair32_kernel<double> (one wave per image pair; 3x3 box sums in registers, one activation map per pixel and layer)",
+                     "bound": "valu", "achieved": ppl / (build_ms * 1e-3), "unit": "pair-pixel-layers/s",
+                     "valu_busy": None if valu is None else valu.get("valu_busy"),
+                     "valu_busy_source": None if valu is None else valu.get("source"),
+                     "peak": None, "frac": None if valu is None else valu.get("valu_busy"), "traffic": None},
+        "cpu_baseline": None,
+    }
+    if rank == 0:
+        out_fd.emit(json.dumps(out))
+
+
+# ----------------------------------------------------------------------------- main
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        launch_ranks(args)                         # never returns; nothing below ran in the parent
     out_fd = _JsonOut()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = int(os.environ.get("WORLD_SIZE", "1")) if "RANK" in os.environ else 1
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
-        args.gpus = world
+    args.gpus = world
 
-    multi = world > 1 or (args.sharded_path and "RANK" in os.environ and "MASTER_ADDR" in os.environ)
-    if multi:
-        # torch (host-side gloo rendezvous only) goes in FIRST: the wheel carries its own ROCm runtime and RCCL, and
-        # loaded in this order libsmnngp.so binds to that same runtime, so the process holds one HIP and one RCCL
-        import torch                               # noqa: F401
-        import torch.distributed                   # noqa: F401
     from smnngp import _lib as L
 
     np_dtype = np.float32 if args.dtype == "f32" else np.float64
@@ -135,68 +300,65 @@ def main():
     n, d, nl = args.n, args.d, args.layers
     ctx = L.Context(local_rank)
 
-    dist = None
-    # `--sharded-path` under torch.distributed.run with ONE rank walks exactly the N>1 code (torch import, gloo
-    # rendezvous, broadcast of the RCCL id, communicator, all-gather) on a one-GPU box
-    if multi:
-        import torch
-        import torch.distributed as dist_mod
-        dist = dist_mod
-        dist.init_process_group("gloo")            # host-side rendezvous only; the data path is RCCL below
-        uid = C.create_string_buffer(128)
-        if rank == 0:
-            assert L._lib.smn_comm_unique_id(uid) == 0, "RCCL unavailable"
-        t = torch.tensor(list(uid.raw), dtype=torch.uint8)
-        dist.broadcast(t, 0)
-        uid = C.create_string_buffer(bytes(t.tolist()), 128)
+    sharded = world > 1 or args.sharded_path
+    if world > 1:
+        path = args.rendezvous_file or os.path.join(
+            tempfile.gettempdir(), "smnngp_uid_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.getppid()))
+        uid = exchange_rccl_id(L, path, rank)
         ctx.call("smn_comm_init", world, rank, uid)
-    elif args.sharded_path:                        # plain `python bench.py --sharded-path`: one-rank communicator, no torch
+    elif args.sharded_path:                        # one-rank communicator: the P>1 code path on a one-GPU box
         uid = C.create_string_buffer(128)
         assert L._lib.smn_comm_unique_id(uid) == 0, "RCCL unavailable"
         ctx.call("smn_comm_init", 1, 0, uid)
+    sync = RankSync(ctx, world, rank)
+
+    if args.config == "c3":
+        bench_conv(args, out_fd, L, ctx, sync, rank, world)
+        if sharded:
+            sync.barrier()
+            ctx.call("smn_comm_destroy")
+        return
 
     rng = np.random.default_rng(0)                 # same seed on every rank: X is replicated
     x = ctx.to_device(rng.standard_normal((n, d)).astype(np_dtype))
     y = ctx.to_device(rng.standard_normal(n).astype(np_dtype))
     lp, quad, logdet, info = C.c_double(), C.c_double(), C.c_double(), C.c_int()
+    res = {}
 
-    sharded = world > 1 or args.sharded_path
     if not sharded:
         def step():
             ctx.call("smn_spr_loss", code, L.NET_MLP, act, nl, 1.0, 1e-8, 1.0, x.ptr, n, d, d, y.ptr, eps, 0.0, 1.0,
                      C.byref(lp), C.byref(quad), C.byref(logdet), C.byref(info))
+            res["v"] = (lp.value, logdet.value, info.value)
+        parts = 0
     else:
-        # Balanced symmetric shard (sharding.py, paired layout): rank r builds the lower trapezoids of row blocks
-        # r and 2P-1-r packed into its chunk of `stage`, ONE in-place RCCL all-gather moves N^2/2-ish elements in
-        # total, smn_lml_from_blocks scatters them straight into the factorisation workspace and factors (replicated).
+        # Balanced symmetric shard (sharding.py, paired layout): rank r builds the lower trapezoids of row blocks r and
+        # 2P-1-r into its own chunk, piece by piece; each finished piece of all ranks is all-gathered and scattered into the
+        # factorisation workspace on the communication stream beside the build of the next one; then every rank factors.
         from smnngp import sharding
-        es = np.dtype(np_dtype).itemsize
-        stage = ctx.empty((world * sharding.paired_chunk_elems(n, world),), np_dtype)
-        hblk = sharding.block_rows(n, world)
+        chunk = sharding.paired_chunk_elems(n, world)
+        mine = ctx.empty((chunk,), np_dtype)
+        stage = ctx.empty((world * chunk,), np_dtype)
+        parts = args.parts or sharding.default_parts(n, world)
+        backend = sharding.DeviceBackend(ctx)
+        spec = (L.NET_MLP, act, nl, 1.0, 1e-8, 1.0)
 
         def step():
-            sharding.build_lower_sharded(ctx, code, es, L.NET_MLP, act, nl, 1.0, 1e-8, 1.0, x.ptr, n, d, d,
-                                         rank, world, stage.ptr, None, 0)
-            ctx.call("smn_lml_from_blocks", code, stage.ptr, n, world, hblk, y.ptr, eps, 0.0, 1.0, C.byref(lp),
-                     C.byref(quad), C.byref(logdet), C.byref(info))
-
-    def barrier():
-        ctx.synchronize()
-        if dist is not None:
-            dist.barrier()
+            v = sharding.lml_sharded_pipelined(backend, code, spec, x.ptr, n, d, d, y.ptr, rank, world, mine.ptr, stage.ptr,
+                                               eps, 0.0, 1.0, parts=parts)
+            res["v"] = (v[0], v[2], v[3])
 
     for _ in range(args.warmup):
         step()
-    barrier()
+    sync.barrier()
     # Timed region: hipEvent pairs around the launches of the DOMINANT kernel only (category 5, the Cholesky trailing
     # update: 79 launches per step).  Pairs around all ~280 launches of a step cost ~2 ms of queue time per step
     # (profiles/r01e_event_overhead.txt), so the other categories are timed in a separate, untimed pass below.
-    CATS = ["prep", "build", "recursion", "panel", "strip", "trail", "misc"]
     ctx.call("smn_profile_enable", 2 << 5)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    barrier()
+    sync.barrier()
     dt = time.perf_counter() - t0
     ms, cnt = C.c_double(), C.c_int()
     ctx.call("smn_profile_read", 5, C.byref(ms), C.byref(cnt))
@@ -211,38 +373,30 @@ def main():
     ctx.call("smn_profile_enable", 1)              # untimed detail pass: every category
     for _ in range(DETAIL_STEPS):
         step()
-    barrier()
-    prof = {}
-    for cat, name in enumerate(CATS):
-        ms, cnt = C.c_double(), C.c_int()
-        ctx.call("smn_profile_read", cat, C.byref(ms), C.byref(cnt))
-        prof[name] = (ms.value / DETAIL_STEPS, cnt.value // DETAIL_STEPS)
+    sync.barrier()
+    prof = read_profile(ctx, DETAIL_STEPS)
     ctx.call("smn_profile_enable", 0)
     prof["trail"] = trail_timed
-    if dist is not None:
-        import torch
-        tt = torch.tensor([dt], dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt = sync.max(dt)
     ms_per_step = dt / args.steps * 1e3
 
     if rank == 0:
-        n_total = n + TILE if world == 1 else n + TILE
+        n_total = n + TILE
         flops_counted = 2.0 * n * n * d + n ** 3 / 3.0                 # Gram 2N^2 d + Cholesky N^3/3
         trail_fl, strip_fl = fl[5], fl[4]
         peak = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_F64_MFMA_TFLOPS
         per = prof                                 # per step: `trail` from the timed region, the rest from the detail pass
         kp = ((d + 31) // 32 * 32) if args.dtype == "f32" else ((d + 15) // 16 * 16)
+        t = n_total // TILE
         if not sharded:
-            t = n_total // TILE
-            build_fl = (t * (t + 1) // 2) * TILE * TILE * 2.0 * kp
+            build_tiles = t * (t + 1) // 2
         else:
             from smnngp import sharding as S_
-            tiles = 0                                                     # lower tiles rank 0's two blocks execute
+            build_tiles = 0                                               # lower tiles rank 0's two blocks execute
             for b in S_.paired_blocks(world, 0):
                 rb_, re_ = S_.block_range(n, world, b)
-                tiles += sum(t + 1 for t in range(rb_ // TILE, -(-re_ // TILE)))
-            build_fl = tiles * TILE * TILE * 2.0 * kp
+                build_tiles += sum(tt + 1 for tt in range(rb_ // TILE, -(-re_ // TILE)))
+        build_fl = build_tiles * TILE * TILE * 2.0 * kp
         trail_ms = per["trail"][0]
         roof = {
             "kernel": ("update_kernel<float,1> + trail_kernel<float> (persistent form, launches over 512 tiles)"
@@ -254,22 +408,21 @@ def main():
             "achieved": trail_fl / (trail_ms * 1e-3) / 1e12 if trail_ms > 0 else None,
             "peak": peak, "unit": "TFLOP/s",
             "frac": (trail_fl / (trail_ms * 1e-3) / 1e12 / peak) if trail_ms > 0 else None,
-            # HBM-side bytes per launch cannot be read without rocprofv3: taken from the committed PMC pass of this
-            # exact workload (profiles/r01f_pmc_traffic.json: FETCH_SIZE x2 + WRITE_SIZE, separate passes), else null
+            # fabric-side bytes per launch cannot be read without rocprofv3: taken from the committed PMC pass of this exact
+            # workload, else null
             "traffic": pmc_traffic(args, sharded),
             "launches_per_step": per["trail"][1], "avg_launch_ms": trail_ms / max(per["trail"][1], 1),
             "flops_per_step": trail_fl,
         }
-        # Look-ahead (default from N=8192): the far updates run on a CU-masked stream (num_cu - SMN_CHAIN_CUS CUs)
-        # BESIDE the next super-panel's panel chain, so the launch durations above overlap with other kernels and
-        # `frac` (kept as the contract defines it) understates the kernel.  Two more readings of the same kernel:
+        # Look-ahead (default from N=8192): the far updates run on a CU-masked stream BESIDE the next super-panel's panel
+        # chain, so the launch durations above overlap with other kernels and `frac` (kept as the contract defines it)
+        # understates the kernel.  Two more readings of the same kernel:
         min_n_env = os.environ.get("SMN_CHAIN_MIN_N")
-        lookahead = n_total >= int(min_n_env or "8192")
-        chol_wall_ms = ms_per_step - per["build"][0] - per["prep"][0] - per["misc"][0]
-        if not sharded:
-            roof["cholesky_wall_ms"] = chol_wall_ms
-            # every MFMA flop of the factorisation (trailing + strip updates) over its wall time, panel chain included
-            roof["cholesky_mfma_frac"] = (trail_fl + strip_fl) / (chol_wall_ms * 1e-3) / 1e12 / peak
+        lookahead = n_total >= int(min_n_env or "8192") and int(os.environ.get("SMN_CHAIN_CUS", "32")) > 0
+        chol_wall_ms = ms_per_step - per["build"][0] - per["prep"][0] - per["misc"][0] - per["exposed"][0]
+        roof["cholesky_wall_ms"] = chol_wall_ms
+        # every MFMA flop of the factorisation (trailing + strip updates) over its wall time, panel chain included
+        roof["cholesky_mfma_frac"] = (trail_fl + strip_fl) / (chol_wall_ms * 1e-3) / 1e12 / peak
         roof["lookahead"] = bool(lookahead)
         if lookahead and not sharded and not args.no_exclusive_probe:
             # the same launches with the look-ahead off (one stream, nothing else on the GPU): an untimed extra pass on a
@@ -307,27 +460,41 @@ def main():
             others["build_kernel (fused Gram + %d-layer recursion, executed tiles)" % nl] = {
                 "bound": "mfma", "achieved": build_fl / (per["build"][0] * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
                 "frac": build_fl / (per["build"][0] * 1e-3) / 1e12 / peak, "ms": per["build"][0]}
+        # what the step EXECUTED on the MFMA (lower-triangle Gram tiles, whole update tiles) over its wall time, beside the
+        # SURVEY-sanctioned counted rate in `value`
+        executed = build_fl + trail_fl + strip_fl
         out = {
             "metric": "kernel-build + Cholesky wallclock (ms) and GFLOP/s at N=%d, %d-layer %s NNGP" % (n, nl, args.act),
             "value": flops_counted / (ms_per_step * 1e-3) / 1e9, "unit": "GFLOP/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "SPR.loss: NNGP kernel build + jittered Cholesky + Gaussian LML, N=%d d=%d L=%d %s"
-                                   % (n, d, nl, args.act),
+            "config": {"workload": "%s: SPR.loss = NNGP kernel build + jittered Cholesky + Gaussian LML, N=%d d=%d L=%d %s"
+                                   % (args.config.upper(), n, d, nl, args.act),
                        "N": n, "d": d, "layers": nl, "act": args.act, "w_std": 1.0, "b_std": 1e-8, "last_w_std": 1.0,
                        "eps_abs": eps, "flops_counted": flops_counted,
-                       "parallelism": "single GPU" if not sharded else "paired lower-block row shards x%d + one RCCL all-gather + replicated Cholesky" % world},
+                       "parallelism": "single GPU" if not sharded else
+                       "paired lower-block row shards x%d, exchange in %d pieces pipelined behind the build (RCCL all-gather per piece), replicated Cholesky" % (world, parts)},
+            "executed_tflops": executed / (ms_per_step * 1e-3) / 1e12,
+            "executed_note": "MFMA flops actually issued per step (lower-triangle Gram tiles + whole update tiles; rank 0's share of the build when sharded) / step time; `value` counts 2N^2 d + N^3/3",
             "phases_ms": {k: round(v[0], 4) for k, v in per.items()},
             "phases_ms_source": "trail: hipEvents in the timed region; others: separate untimed pass with events on every launch",
-            # the north-star's "kernel-build speed-up at N GPUs" reads off these two (rank 0; every rank builds the same
-            # number of tiles): the fused Gram + recursion launch of this rank's shard, and all-gather + scatter
-            "kernel_build_ms": round(per["build"][0], 4), "exchange_ms": round(per["misc"][0], 4) if sharded else 0.0,
-            "result": {"logpdf": lp.value, "logdet": logdet.value, "info": info.value},
+            "result": {"logpdf": res["v"][0], "logdet": res["v"][1], "info": res["v"][2]},
             "roofline": roof,
         }
+        if sharded:
+            # The north-star's "kernel-build speed-up at N GPUs", stated INCLUDING the exchange: this rank's build launches,
+            # the all-gathers (they run beside the build), the scatter into the workspace, and what of all that the main
+            # stream had to wait for after its last build launch (`exposed`).  The one-GPU lower build of the same shape for
+            # the ratio is `phases_ms.build` of the N=1 line.
+            out["kernel_build_ms"] = round(per["build"][0], 4)
+            out["exchange_ms"] = round(per["comm"][0], 4)
+            out["scatter_ms"] = round(per["misc"][0], 4)
+            out["exchange_exposed_ms"] = round(per["exposed"][0], 4)
+            out["build_plus_assemble_ms"] = round(per["build"][0] + per["prep"][0] + per["exposed"][0], 4)
+            out["exchange_parts"] = parts
         # stand-alone recursion (a3): HBM roofline probe on a stored K0, outside the timed region
-        if world == 1 and not args.no_recursion_probe:
+        if world == 1 and not sharded and not args.no_recursion_probe:
             try:
                 k0 = ctx.empty((n, n), np_dtype); kk = ctx.empty((n, n), np_dtype)
                 q1 = ctx.empty((n,), np_dtype)
@@ -362,14 +529,13 @@ def main():
                 others["recursion_kernel"] = {"error": str(e)}
         out["roofline_other_kernels"] = others
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args, np_dtype, eps, lp.value)
+            out["cpu_baseline"] = cpu_baseline(args, np_dtype, eps, res["v"][0])
         elif world == 1:
             out["cpu_baseline"] = None
         out_fd.emit(json.dumps(out))
-    if dist is not None:
-        dist.barrier()
+    if sharded:
+        sync.barrier()
         ctx.call("smn_comm_destroy")
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

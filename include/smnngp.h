@@ -61,7 +61,8 @@ int smn_timer_start(smn_ctx* ctx);
 int smn_timer_stop_ms(smn_ctx* ctx, double* ms);           /* synchronises */
 /* per-kernel timing: while enabled kernel launches are bracketed by a hipEvent pair on their own
  * stream.  category: 0 prep (pad/tables), 1 fused Gram+recursion build, 2 stand-alone recursion,
- * 3 Cholesky panel, 4 Cholesky strip update, 5 Cholesky trailing update, 6 other.
+ * 3 Cholesky panel, 4 Cholesky strip update, 5 Cholesky trailing update, 6 other (scatter of gathered blocks),
+ * 7 all-gathers, 8 the wait of the main stream for the last piece of a pipelined exchange (its exposed part).
  * on: 0 off; 1 every category; (2 << c) only category c (values add up to a mask).  An event pair
  * costs a few microseconds of queue time per launch, so timing ONE category perturbs a step far less
  * than timing all ~280 launches of it. */
@@ -239,6 +240,40 @@ int smn_unpack_lower_blocks(smn_ctx* ctx, int dtype, const void* stage_d, int64_
  * scattered straight into the factorisation workspace, K is never assembled separately. */
 int smn_lml_from_blocks(smn_ctx* ctx, int dtype, const void* stage_d, int64_t n, int nranks,
                         int64_t block_rows, const void* y_d, double eps_abs, double df, double scale,
+                        double* logpdf_h, double* quad_h, double* logdet_h, int* info_h);
+/* nranks / rank of the context's communicator (1 / 0 without one). */
+int smn_comm_info(smn_ctx* ctx, int* nranks, int* rank);
+
+/* ---- pipelined exchange: the all-gather rides behind the build, piece by piece ----
+ * A rank's chunk (block_rows^2 (2 nranks + 1) elements, low block first) is cut into `parts` equal pieces (element
+ * ranges; parts must divide the chunk into multiples of 4 elements).  The rank builds the tile rows that complete
+ * piece g (host side: sharding.py part_tile_rows) into its own contiguous chunk `mine_d`, piece g of all ranks is
+ * gathered into stage_d laid out [parts][nranks][piece] and scattered into K while piece g+1 is being built.
+ *   smn_kernel_mlp_shard_rows   smn_kernel_mlp_shard restricted to tile rows [lo_t0,lo_t1) of the low block and
+ *                               [hi_t0,hi_t1) of the high block (128-row tiles from the block's first row);
+ *                               reuse_operand != 0 skips the padding of x (same x as the previous shard call)
+ *   smn_allgather_part          piece `part`: mine_d + part*piece  ->  stage_d + part*nranks*piece, context's stream
+ *   smn_unpack_lower_parts      pieces [part_begin, part_end) of stage_d -> lower triangle of k_d [n,n], context's stream
+ *   smn_shard_begin             the factorisation workspace of smn_lml_from_shards, made ready before the first piece
+ *   smn_shard_exchange_part     all-gather + scatter of one piece into that workspace on the context's COMMUNICATION
+ *                               stream, ordered after everything issued so far on its main stream; returns at once.
+ *                               nranks must equal the communicator's size (SMN_ECOMM otherwise: a world > 1 call on a
+ *                               context without a communicator would gather nothing)
+ *   smn_lml_from_shards         waits for the last piece, then factorisation + head: same outputs as smn_lml */
+int smn_kernel_mlp_shard_rows(smn_ctx* ctx, int dtype, int net, int act, int num_hiddens,
+                              double w_std, double b_std, double last_w_std,
+                              const void* x_d, int64_t n, int64_t ldx, int64_t d,
+                              int nranks, int rank, int64_t block_rows,
+                              int64_t lo_t0, int64_t lo_t1, int64_t hi_t0, int64_t hi_t1, int reuse_operand,
+                              int get_mask, void* nngp_chunk_d, void* ntk_chunk_d);
+int smn_allgather_part(smn_ctx* ctx, int dtype, const void* mine_d, void* stage_d, int64_t chunk_elems,
+                       int parts, int part);
+int smn_unpack_lower_parts(smn_ctx* ctx, int dtype, const void* stage_d, int64_t n, int nranks,
+                           int64_t block_rows, int parts, int part_begin, int part_end, void* k_d, int64_t ldk);
+int smn_shard_begin(smn_ctx* ctx, int dtype, int64_t n);
+int smn_shard_exchange_part(smn_ctx* ctx, int dtype, const void* mine_d, void* stage_d, int64_t n, int nranks,
+                            int64_t block_rows, int parts, int part);
+int smn_lml_from_shards(smn_ctx* ctx, int dtype, int64_t n, const void* y_d, double eps_abs, double df, double scale,
                         double* logpdf_h, double* quad_h, double* logdet_h, int* info_h);
 
 #ifdef __cplusplus

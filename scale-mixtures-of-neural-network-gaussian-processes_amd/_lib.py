@@ -85,6 +85,14 @@ PROTOTYPES = {
     "smn_allgather": [_vp, _i, _vp, _vp, _i64],
     "smn_unpack_lower_blocks": [_vp, _i, _vp, _i64, _i, _i64, _vp, _i64],
     "smn_lml_from_blocks": [_vp, _i, _vp, _i64, _i, _i64, _vp, _d, _d, _d, _pd, _pd, _pd, _pi],
+    "smn_comm_info": [_vp, _pi, _pi],
+    "smn_kernel_mlp_shard_rows": [_vp, _i, _i, _i, _i, _d, _d, _d, _vp, _i64, _i64, _i64, _i, _i, _i64, _i64, _i64, _i64, _i64,
+                                  _i, _i, _vp, _vp],
+    "smn_allgather_part": [_vp, _i, _vp, _vp, _i64, _i, _i],
+    "smn_unpack_lower_parts": [_vp, _i, _vp, _i64, _i, _i64, _i, _i, _i, _vp, _i64],
+    "smn_shard_begin": [_vp, _i, _i64],
+    "smn_shard_exchange_part": [_vp, _i, _vp, _vp, _i64, _i, _i64, _i, _i],
+    "smn_lml_from_shards": [_vp, _i, _i64, _vp, _d, _d, _d, _pd, _pd, _pd, _pi],
 }
 for _name, _args in PROTOTYPES.items():
     _fn = getattr(_lib, _name)          # AttributeError here == a symbol the header declares is missing

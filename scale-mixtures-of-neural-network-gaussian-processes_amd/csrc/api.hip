@@ -5,6 +5,7 @@ int smn_workspace(smn_ctx* ctx, int slot, size_t bytes, void** out) {
   if (slot < 0 || slot >= smn_ctx::kSlots) return smn_fail(ctx, SMN_EINVAL, "bad workspace slot");
   if (ctx->ws_bytes[slot] < bytes) {
     if (ctx->ws[slot]) {
+      if (ctx->stream_comm) SMN_HIP(ctx, hipStreamSynchronize(ctx->stream_comm));
       SMN_HIP(ctx, hipStreamSynchronize(ctx->stream));
       SMN_HIP(ctx, hipFree(ctx->ws[slot]));
       ctx->ws[slot] = nullptr;
@@ -239,6 +240,9 @@ extern "C" int smn_ctx_create(int device_id, smn_ctx** out) {
   bool ok = main_ok &&
             hipEventCreateWithFlags(&c->ev_a, hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&c->ev_b, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&c->ev_c0, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&c->ev_c1, hipEventDisableTiming) == hipSuccess &&
+            hipStreamCreateWithFlags(&c->stream_comm, hipStreamNonBlocking) == hipSuccess &&
             hipEventCreate(&c->ev_t0) == hipSuccess && hipEventCreate(&c->ev_t1) == hipSuccess &&
             hipMalloc(reinterpret_cast<void**>(&c->d_scal), 64 * sizeof(double)) == hipSuccess &&
             hipMalloc(reinterpret_cast<void**>(&c->d_info), 16 * sizeof(int)) == hipSuccess &&
@@ -256,6 +260,7 @@ extern "C" int smn_ctx_destroy(smn_ctx* c) {
   if (!c) return SMN_OK;
   (void)hipSetDevice(c->device);
   if (c->stream_bulk) (void)hipStreamSynchronize(c->stream_bulk);
+  if (c->stream_comm) (void)hipStreamSynchronize(c->stream_comm);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->comm) smn_comm_destroy(c);
   for (int i = 0; i < smn_ctx::kSlots; ++i)
@@ -266,6 +271,9 @@ extern "C" int smn_ctx_destroy(smn_ctx* c) {
   if (c->h_mail) (void)hipHostFree(c->h_mail);
   if (c->ev_a) (void)hipEventDestroy(c->ev_a);
   if (c->ev_b) (void)hipEventDestroy(c->ev_b);
+  if (c->ev_c0) (void)hipEventDestroy(c->ev_c0);
+  if (c->ev_c1) (void)hipEventDestroy(c->ev_c1);
+  if (c->stream_comm) (void)hipStreamDestroy(c->stream_comm);
   if (c->ev_t0) (void)hipEventDestroy(c->ev_t0);
   if (c->ev_t1) (void)hipEventDestroy(c->ev_t1);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -300,6 +308,7 @@ extern "C" int smn_free(smn_ctx* ctx, void* dptr) {
   if (!ctx) return SMN_EINVAL;
   SMN_ENTER(ctx);
   if (!dptr) return SMN_OK;
+  if (ctx->stream_comm) SMN_HIP(ctx, hipStreamSynchronize(ctx->stream_comm));   // a piece of it may still be in flight
   SMN_HIP(ctx, hipStreamSynchronize(ctx->stream));
   SMN_HIP(ctx, hipFree(dptr));
   return SMN_OK;

@@ -463,7 +463,12 @@ __global__ void __launch_bounds__(256, BN == 64 ? 4 : (BM == 64 ? (sizeof(T) == 
         t.acc[m][n][i] = -u.a[gr * u.lda + gc];
       }
   // trailing updates (TAG 1) run K = 256 ... 1024: the pipelined K loop; strips (K = 128) the plain one
+#ifdef SMN_DEBUG_SAMEPANEL   // timing experiment only (WRONG results): every tile reads one of 8 operand panels, so all hit L2
+  t.template mainloop<TAG == 1 ? 1 : 0>(u.a + (u.r0 + (row0 - u.r0) % 1024) * u.lda + u.k0, u.lda,
+                                        u.a + (u.c0 + (col0 - u.c0) % 1024) * u.lda + u.k0, u.lda, u.K, smem);
+#else
   t.template mainloop<TAG == 1 ? 1 : 0>(u.a + row0 * u.lda + u.k0, u.lda, u.a + col0 * u.lda + u.k0, u.lda, u.K, smem);
+#endif
 #pragma unroll
   for (int m = 0; m < Tile::MT; ++m)
 #pragma unroll

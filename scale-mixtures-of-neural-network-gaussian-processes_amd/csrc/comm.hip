@@ -106,21 +106,35 @@ extern "C" int smn_comm_destroy(smn_ctx* ctx) {
   return SMN_OK;
 }
 
+extern "C" int smn_comm_info(smn_ctx* ctx, int* nranks, int* rank) {
+  if (!ctx) return SMN_EINVAL;
+  if (nranks) *nranks = ctx->comm ? ctx->nranks : 1;
+  if (rank) *rank = ctx->comm ? ctx->rank : 0;
+  return SMN_OK;
+}
+
+namespace {
+// all-gather of `count` elements per rank on `st`; without a communicator (one rank) it is a copy
+int allgather_on(smn_ctx* ctx, hipStream_t st, int dtype, const void* send_d, void* recv_d, int64_t count) {
+  if (!ctx->comm) {
+    if (send_d != recv_d)
+      SMN_HIP(ctx, hipMemcpyAsync(recv_d, send_d, dtype_size(dtype) * (size_t)count, hipMemcpyDeviceToDevice, st));
+    return SMN_OK;
+  }
+  Rccl& r = rccl();
+  const int rc = r.AllGather(send_d, recv_d, (size_t)count, dtype == SMN_F64 ? kNcclFloat64 : kNcclFloat32,
+                             static_cast<nccl_comm>(ctx->comm), st);
+  if (rc != 0) return smn_fail(ctx, SMN_ECOMM, "ncclAllGather: %s", r.GetErrorString ? r.GetErrorString(rc) : "?");
+  return SMN_OK;
+}
+}  // namespace
+
 extern "C" int smn_allgather(smn_ctx* ctx, int dtype, const void* send_d, void* recv_d, int64_t count) {
   if (!ctx || !send_d || !recv_d || count <= 0) return SMN_EINVAL;
   SMN_ENTER(ctx);
   if (dtype != SMN_F32 && dtype != SMN_F64) return smn_fail(ctx, SMN_EINVAL, "bad dtype");
-  if (!ctx->comm) {  // single rank: the gather is a copy
-    if (send_d != recv_d)
-      SMN_HIP(ctx, hipMemcpyAsync(recv_d, send_d, dtype_size(dtype) * (size_t)count, hipMemcpyDeviceToDevice, ctx->stream));
-    return SMN_OK;
-  }
-  Rccl& r = rccl();
-  ProfScope ps(ctx, PROF_MISC, ctx->stream);   // phases_ms.misc of bench.py = gather + unpack
-  const int rc = r.AllGather(send_d, recv_d, (size_t)count, dtype == SMN_F64 ? kNcclFloat64 : kNcclFloat32,
-                             static_cast<nccl_comm>(ctx->comm), ctx->stream);
-  if (rc != 0) return smn_fail(ctx, SMN_ECOMM, "ncclAllGather: %s", r.GetErrorString ? r.GetErrorString(rc) : "?");
-  return SMN_OK;
+  ProfScope ps(ctx, PROF_COMM, ctx->stream);
+  return allgather_on(ctx, ctx->stream, dtype, send_d, recv_d, count);
 }
 
 // ---------------------------------------------------------------- paired lower-trapezoid blocks
@@ -186,4 +200,114 @@ extern "C" int smn_unpack_lower_blocks(smn_ctx* ctx, int dtype, const void* stag
 #undef UNPACK
   SMN_CHECK_LAUNCH(ctx);
   return SMN_OK;
+}
+
+// ---------------------------------------------------------------- pipelined exchange: pieces of the chunks
+// Every rank's chunk (block_rows^2 (2P+1) elements, low block first) is cut into `parts` equal pieces.  Piece g of all
+// ranks is gathered as soon as the rank has built the tile rows it covers (sharding.py: part_tile_rows), into
+//   stage[g][rank][piece]          (piece = chunk / parts elements)
+// while the next piece is being built; a piece's scatter into K follows its gather on the same stream.  Pieces are
+// element ranges, not row ranges: the mapping below undoes the packing element by element (in 16-byte vectors: a
+// block's leading dimension and the piece length are multiples of 4 elements, so a vector never straddles a row or
+// a piece).
+namespace {
+
+template <typename T, int VEC>
+__global__ void unpack_part_kernel(const T* __restrict__ stage_g, int64_t piece, int64_t e0, int64_t h, int P, int64_t n,
+                                   T* __restrict__ k, int64_t ldk) {
+  const int64_t v = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * VEC;   // element inside [rank][piece]
+  if (v >= (int64_t)P * piece) return;
+  const int64_t r = v / piece;                 // owner rank
+  int64_t e = e0 + (v - r * piece);            // element of rank r's chunk
+  const int64_t low = h * (r + 1) * h;         // elements of its low block
+  int64_t b, ld;
+  if (e < low) {
+    b = r; ld = (r + 1) * h;
+  } else {
+    e -= low; b = 2 * (int64_t)P - 1 - r; ld = (2 * (int64_t)P - r) * h;
+  }
+  const int64_t row = b * h + e / ld, col = e % ld;
+  if (row >= n) return;
+  int64_t cend = (row / kTile + 1) * kTile;
+  if (cend > n) cend = n;
+  if (col >= cend) return;
+  T* dst = k + row * ldk + col;
+  const T* src = stage_g + v;
+  if (VEC > 1 && col + VEC <= cend) {
+    typedef T vec_t __attribute__((ext_vector_type(VEC)));
+    *reinterpret_cast<vec_t*>(dst) = *reinterpret_cast<const vec_t*>(src);
+  } else {
+    for (int i = 0; i < VEC && col + i < cend; ++i) dst[i] = src[i];
+  }
+}
+
+int check_parts(smn_ctx* ctx, int dtype, int64_t n, int nranks, int64_t block_rows, int parts, int64_t* piece) {
+  if (dtype != SMN_F32 && dtype != SMN_F64) return smn_fail(ctx, SMN_EINVAL, "bad dtype");
+  if (n <= 0 || nranks <= 0 || block_rows <= 0 || block_rows % kTile || 2 * (int64_t)nranks * block_rows < n)
+    return smn_fail(ctx, SMN_EINVAL, "bad shard geometry (n=%lld ranks=%d block_rows=%lld)", (long long)n, nranks,
+                    (long long)block_rows);
+  const int64_t chunk = block_rows * block_rows * (2 * (int64_t)nranks + 1);
+  if (parts <= 0 || chunk % parts || (chunk / parts) % 4)
+    return smn_fail(ctx, SMN_EINVAL, "parts=%d must divide the chunk (%lld elements) into multiples of 4", parts, (long long)chunk);
+  *piece = chunk / parts;
+  return SMN_OK;
+}
+
+}  // namespace
+
+int unpack_parts_on(smn_ctx* ctx, hipStream_t st, int dtype, const void* stage_d, int64_t n, int nranks, int64_t block_rows,
+                    int parts, int part_begin, int part_end, void* k_d, int64_t ldk) {
+  int64_t piece = 0;
+  SMN_TRY(check_parts(ctx, dtype, n, nranks, block_rows, parts, &piece));
+  if (part_begin < 0 || part_end > parts || part_begin > part_end || ldk < n)
+    return smn_fail(ctx, SMN_EINVAL, "unpack: bad part range [%d,%d) of %d or ldk", part_begin, part_end, parts);
+  const size_t es = dtype_size(dtype);
+  const int vec = (int)(16 / es);
+  const bool aligned = (ldk % vec == 0) && (reinterpret_cast<uintptr_t>(k_d) % 16 == 0) &&
+                       (reinterpret_cast<uintptr_t>(stage_d) % 16 == 0);
+  for (int g = part_begin; g < part_end; ++g) {
+    const char* sg = static_cast<const char*>(stage_d) + es * (size_t)g * (size_t)nranks * (size_t)piece;
+    const int64_t total = (int64_t)nranks * piece;
+#define UNPACKP(T, V)                                                                                          \
+  hipLaunchKernelGGL((unpack_part_kernel<T, V>), dim3((unsigned)((total / V + 255) / 256)), dim3(256), 0, st, \
+                     reinterpret_cast<const T*>(sg), piece, (int64_t)g * piece, block_rows, nranks, n,        \
+                     static_cast<T*>(k_d), ldk)
+    if (dtype == SMN_F64) {
+      if (aligned) UNPACKP(double, 2); else UNPACKP(double, 1);
+    } else {
+      if (aligned) UNPACKP(float, 4); else UNPACKP(float, 1);
+    }
+#undef UNPACKP
+  }
+  SMN_CHECK_LAUNCH(ctx);
+  return SMN_OK;
+}
+
+int allgather_part_on(smn_ctx* ctx, hipStream_t st, int dtype, const void* mine_d, void* stage_d, int64_t chunk_elems,
+                      int parts, int part) {
+  if (parts <= 0 || part < 0 || part >= parts || chunk_elems % parts)
+    return smn_fail(ctx, SMN_EINVAL, "allgather_part: part %d of %d over %lld elements", part, parts, (long long)chunk_elems);
+  const int64_t piece = chunk_elems / parts;
+  const int P = ctx->comm ? ctx->nranks : 1;
+  const size_t es = dtype_size(dtype);
+  const char* send = static_cast<const char*>(mine_d) + es * (size_t)part * (size_t)piece;
+  char* recv = static_cast<char*>(stage_d) + es * (size_t)part * (size_t)P * (size_t)piece;
+  return allgather_on(ctx, st, dtype, send, recv, piece);
+}
+
+extern "C" int smn_unpack_lower_parts(smn_ctx* ctx, int dtype, const void* stage_d, int64_t n, int nranks,
+                                      int64_t block_rows, int parts, int part_begin, int part_end, void* k_d, int64_t ldk) {
+  if (!ctx || !stage_d || !k_d) return SMN_EINVAL;
+  SMN_ENTER(ctx);
+  ProfScope ps(ctx, PROF_MISC, ctx->stream);
+  return unpack_parts_on(ctx, ctx->stream, dtype, stage_d, n, nranks, block_rows, parts, part_begin, part_end, k_d, ldk);
+}
+
+extern "C" int smn_allgather_part(smn_ctx* ctx, int dtype, const void* mine_d, void* stage_d, int64_t chunk_elems,
+                                  int parts, int part) {
+  if (!ctx || !mine_d || !stage_d) return SMN_EINVAL;
+  SMN_ENTER(ctx);
+  if (dtype != SMN_F32 && dtype != SMN_F64) return smn_fail(ctx, SMN_EINVAL, "bad dtype");
+  ProfScope ps(ctx, PROF_COMM, ctx->stream);
+  return allgather_part_on(ctx, ctx->stream, dtype, mine_d, stage_d, chunk_elems, parts, part);
 }

@@ -19,7 +19,11 @@ struct smn_ctx {
   hipStream_t stream_bulk = nullptr;  // CU-masked stream of the far updates F1: may not use the first chain_cus CUs
   int chain_cus = 32;                 // CUs kept free for the panel chain (env SMN_CHAIN_CUS; 0 = no look-ahead)
   int64_t chain_min_n = 8192;         // look-ahead only from this matrix size on (env SMN_CHAIN_MIN_N)
+  hipStream_t stream_comm = nullptr;  // the pipelined exchange: all-gather + scatter of one piece while the next one is being built
   hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
+  hipEvent_t ev_c0 = nullptr, ev_c1 = nullptr;   // main -> comm (piece built), comm -> main (all pieces scattered)
+  // factorisation workspace prepared by smn_shard_begin for the pipelined exchange (slot 2)
+  void* shard_a = nullptr; int64_t shard_lda = 0, shard_n = 0; int shard_dtype = -1;
   std::string err;
   // cached workspace arenas (grown on demand, freed with the context)
   static constexpr int kSlots = 10;
@@ -40,7 +44,7 @@ struct smn_ctx {
   std::vector<hipEvent_t> prof_ev;   // pool, used pairwise
   std::vector<int> prof_cat;         // category of pair i
   size_t prof_used = 0;              // events handed out
-  double prof_flops[8] = {};         // MFMA flops EXECUTED per category since smn_profile_enable (whole tiles; host-side count)
+  double prof_flops[10] = {};         // MFMA flops EXECUTED per category since smn_profile_enable (whole tiles; host-side count)
   int num_cu = 256;                  // hipDeviceProp_t::multiProcessorCount
   int64_t super_panel = 1024;        // columns per super-panel of the two-level Cholesky (env SMN_SUPER)
   // structural-zero hint for the factorisation in flight: appended rows [id0, id1) hold an identity block
@@ -59,7 +63,7 @@ struct smn_ctx {
 };
 
 enum { PROF_PREP = 0, PROF_BUILD = 1, PROF_RECURSION = 2, PROF_PANEL = 3, PROF_STRIP = 4, PROF_TRAIL = 5,
-       PROF_MISC = 6, PROF_NCAT = 7 };
+       PROF_MISC = 6, PROF_COMM = 7, PROF_EXPOSED = 8, PROF_NCAT = 9 };
 
 // Brackets the launches issued during its lifetime with an event pair when profiling is on.
 struct ProfScope {

@@ -214,6 +214,76 @@ extern "C" int smn_lml_from_blocks(smn_ctx* ctx, int dtype, const void* stage_d,
   return SMN_OK;
 }
 
+// ---- the pipelined multi-GPU route ("chunk by row-panels and overlap with compute") ----
+//   smn_shard_begin            factorisation workspace up (padding rows cleared), before the first piece arrives
+//   smn_kernel_mlp_shard_rows  (kernel_build.hip) this rank builds the tile rows that complete the next piece
+//   smn_shard_exchange_part    that piece: all-gather + scatter into the workspace, on the communication stream,
+//                              ordered after the build launches issued so far -- the next piece's build runs beside it
+//   smn_lml_from_shards        the context's stream waits for the last piece, then the factorisation and the head
+extern "C" int smn_shard_begin(smn_ctx* ctx, int dtype, int64_t n) {
+  if (!ctx) return SMN_EINVAL;
+  SMN_ENTER(ctx);
+  if (dtype != SMN_F32 && dtype != SMN_F64) return smn_fail(ctx, SMN_EINVAL, "bad dtype");
+  if (n <= 0) return smn_fail(ctx, SMN_EINVAL, "smn_shard_begin: empty");
+  Aug g;
+  SMN_TRY(aug_alloc(ctx, dtype, n, 0, 1, &g));
+  SMN_HIP(ctx, hipMemsetAsync(g.at(n, 0), 0, g.es * (size_t)(g.n_total - n) * (size_t)g.lda, ctx->stream));
+  SMN_TRY(fill_identity_pad(ctx, dtype, g.a, g.lda, g.n_pad, n));
+  ctx->shard_a = g.a; ctx->shard_lda = g.lda; ctx->shard_n = n; ctx->shard_dtype = dtype;
+  return SMN_OK;
+}
+
+extern "C" int smn_shard_exchange_part(smn_ctx* ctx, int dtype, const void* mine_d, void* stage_d, int64_t n, int nranks,
+                                       int64_t block_rows, int parts, int part) {
+  if (!ctx || !mine_d || !stage_d) return SMN_EINVAL;
+  SMN_ENTER(ctx);
+  if (!ctx->shard_a || ctx->shard_n != n || ctx->shard_dtype != dtype)
+    return smn_fail(ctx, SMN_EINVAL, "smn_shard_exchange_part: smn_shard_begin(dtype, n) first");
+  const int P = ctx->comm ? ctx->nranks : 1;
+  if (nranks != P)   // a world > 1 call on a context without a communicator would quietly gather nothing
+    return smn_fail(ctx, SMN_ECOMM, "smn_shard_exchange_part: %d ranks asked for, the context's communicator has %d", nranks, P);
+  const int64_t chunk = block_rows * block_rows * (2 * (int64_t)nranks + 1);
+  hipStream_t sc = ctx->stream_comm;
+  SMN_HIP(ctx, hipEventRecord(ctx->ev_c0, ctx->stream));      // the piece is built (and, for part 0, the workspace is up)
+  SMN_HIP(ctx, hipStreamWaitEvent(sc, ctx->ev_c0, 0));
+  {
+    ProfScope ps(ctx, PROF_COMM, sc);
+    SMN_TRY(allgather_part_on(ctx, sc, dtype, mine_d, stage_d, chunk, parts, part));
+  }
+  {
+    ProfScope ps(ctx, PROF_MISC, sc);
+    SMN_TRY(unpack_parts_on(ctx, sc, dtype, stage_d, n, nranks, block_rows, parts, part, part + 1, ctx->shard_a, ctx->shard_lda));
+  }
+  SMN_HIP(ctx, hipEventRecord(ctx->ev_c1, sc));
+  return SMN_OK;
+}
+
+extern "C" int smn_lml_from_shards(smn_ctx* ctx, int dtype, int64_t n, const void* y_d, double eps_abs, double df,
+                                   double scale, double* logpdf_h, double* quad_h, double* logdet_h, int* info_h) {
+  if (!ctx || !y_d) return SMN_EINVAL;
+  SMN_ENTER(ctx);
+  if (!ctx->shard_a || ctx->shard_n != n || ctx->shard_dtype != dtype)
+    return smn_fail(ctx, SMN_EINVAL, "smn_lml_from_shards: smn_shard_begin(dtype, n) first");
+  if (df > 0.0 && !(scale > 0.0)) return smn_fail(ctx, SMN_EINVAL, "smn_lml_from_shards: scale must be > 0");
+  {
+    // what of the exchange is NOT hidden behind the build: the time this stream spends waiting for the last piece
+    ProfScope ps(ctx, PROF_EXPOSED, ctx->stream);
+    SMN_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_c1, 0));
+  }
+  Aug g;
+  SMN_TRY(aug_alloc(ctx, dtype, n, 0, 1, &g));       // the same slot and size: no reallocation
+  if (g.a != ctx->shard_a) return smn_fail(ctx, SMN_EINVAL, "smn_lml_from_shards: the workspace moved since smn_shard_begin");
+  ctx->shard_a = nullptr;
+  double quad = 0.0, ld = 0.0;
+  int info = 0;
+  SMN_TRY(aug_finish(ctx, dtype, g, y_d, 1, n, eps_abs, 0.0, nullptr, nullptr, 0, &quad, &ld, &info));
+  if (logpdf_h) *logpdf_h = logpdf_from(quad, ld, n, df, scale, info);
+  if (quad_h) *quad_h = quad;
+  if (logdet_h) *logdet_h = ld;
+  if (info_h) *info_h = info;
+  return SMN_OK;
+}
+
 int predict_joint(smn_ctx* ctx, int dtype, void* kj_d, int64_t n, int64_t t, int64_t ldk, const void* y_d, int64_t c,
                   double ridge_rel, double ridge_abs, void* mean_d, void* cov_d, int64_t ldcov, double* quad_h,
                   double* logdet_h, int* info_h, bool td_identity) {

@@ -72,3 +72,8 @@ int transpose_matrix(smn_ctx* ctx, int dtype, void* dst, int64_t ldd, const void
 int flip_transpose_lower(smn_ctx* ctx, int dtype, void* dst, int64_t ldd, const void* src, int64_t lds, int64_t n);
 int transpose_flip(smn_ctx* ctx, int dtype, void* dst, int64_t ldd, const void* src, int64_t lds, int64_t rows,
                    int64_t cols, int flip_src_rows, int flip_dst_rows);
+// pipelined exchange (comm.hip): piece `part` of every rank's chunk, on stream `st`
+int allgather_part_on(smn_ctx* ctx, hipStream_t st, int dtype, const void* mine_d, void* stage_d, int64_t chunk_elems,
+                      int parts, int part);
+int unpack_parts_on(smn_ctx* ctx, hipStream_t st, int dtype, const void* stage_d, int64_t n, int nranks, int64_t block_rows,
+                    int parts, int part_begin, int part_end, void* k_d, int64_t ldk);

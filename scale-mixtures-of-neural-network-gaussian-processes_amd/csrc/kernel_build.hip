@@ -883,25 +883,34 @@ extern "C" int smn_kernel_mlp_lower_rows(smn_ctx* ctx, int dtype, int net, int a
                       nngp_rows_d, ntk_rows_d, ldk, nullptr, nullptr, true);
 }
 
-extern "C" int smn_kernel_mlp_shard(smn_ctx* ctx, int dtype, int net, int act, int num_hiddens, double w_std,
-                                    double b_std, double last_w_std, const void* x_d, int64_t n, int64_t ldx,
-                                    int64_t d, int nranks, int rank, int64_t block_rows, int get_mask,
-                                    void* nngp_chunk_d, void* ntk_chunk_d) {
-  SMN_TRY(check_common(ctx, dtype, n, 1, d));
-  SMN_ENTER(ctx);
+// Tile rows [lo_t0, lo_t1) of this rank's low block and [hi_t0, hi_t1) of its high block (128-row tiles counted from
+// the block's first row), written into the rank's packed chunk.  reuse_operand != 0: the padded copy of x and its row
+// norms left in the workspace by the previous shard call of this context are used as they are (same x, n, d) -- the
+// pieces of one pipelined build pad once.
+static int shard_rows(smn_ctx* ctx, int dtype, int net, int act, int num_hiddens, double w_std, double b_std,
+                      double last_w_std, const void* x_d, int64_t n, int64_t ldx, int64_t d, int nranks, int rank,
+                      int64_t block_rows, int64_t lo_t0, int64_t lo_t1, int64_t hi_t0, int64_t hi_t1, int reuse_operand,
+                      int get_mask, void* nngp_chunk_d, void* ntk_chunk_d) {
   if (nranks <= 0 || rank < 0 || rank >= nranks || block_rows <= 0 || block_rows % kTile ||
       2 * (int64_t)nranks * block_rows < n)
     return smn_fail(ctx, SMN_EINVAL, "smn_kernel_mlp_shard: bad geometry (n=%lld ranks=%d rank=%d block_rows=%lld)",
                     (long long)n, nranks, rank, (long long)block_rows);
   if (!x_d || ((get_mask & SMN_GET_NNGP) && !nngp_chunk_d) || ((get_mask & SMN_GET_NTK) && !ntk_chunk_d))
     return smn_fail(ctx, SMN_EINVAL, "smn_kernel_mlp_shard: null pointer");
+  const int64_t tpb = block_rows / kTile;
+  if (lo_t0 < 0 || lo_t1 > tpb || lo_t0 > lo_t1 || hi_t0 < 0 || hi_t1 > tpb || hi_t0 > hi_t1)
+    return smn_fail(ctx, SMN_EINVAL, "smn_kernel_mlp_shard_rows: tile rows [%lld,%lld) / [%lld,%lld) of %lld per block",
+                    (long long)lo_t0, (long long)lo_t1, (long long)hi_t0, (long long)hi_t1, (long long)tpb);
   const size_t es = dtype_size(dtype);
   const int64_t kp = k_pad(dtype, d), r1 = round_up(n, kTile), h = block_rows;
   void* xs = nullptr;
-  SMN_TRY(smn_workspace(ctx, 0, es * (size_t)kp * (size_t)r1 + sizeof(double) * (size_t)r1, &xs));
+  const size_t xbytes = es * (size_t)kp * (size_t)r1 + sizeof(double) * (size_t)r1;
+  if (reuse_operand && ctx->ws_bytes[0] < xbytes)
+    return smn_fail(ctx, SMN_EINVAL, "smn_kernel_mlp_shard_rows: reuse_operand without a prepared operand");
+  SMN_TRY(smn_workspace(ctx, 0, xbytes, &xs));
   double* q1 = static_cast<double*>(xs);
   char* x1p = reinterpret_cast<char*>(q1 + r1);
-  SMN_TRY(pad_rows(ctx, dtype, x_d, n, ldx, d, x1p, r1, kp, q1));
+  if (!reuse_operand) SMN_TRY(pad_rows(ctx, dtype, x_d, n, ldx, d, x1p, r1, kp, q1));
   BuildCall c{};
   c.spec = BuildSpec{dtype, net, act, num_hiddens, w_std, b_std, last_w_std};
   c.kp = (int)kp; c.d = d; c.get_mask = get_mask;
@@ -911,16 +920,43 @@ extern "C" int smn_kernel_mlp_shard(smn_ctx* ctx, int dtype, int net, int act, i
   c.store_mode = STORE_BOUNDS; c.out_rows = n; c.out_cols = n;
   c.shard = 1;
   const int64_t blk[2] = {rank, 2 * (int64_t)nranks - 1 - rank};
+  const int64_t t0[2] = {lo_t0, hi_t0}, t1[2] = {lo_t1, hi_t1};
   for (int w = 0; w < 2; ++w) {
-    const int64_t rb = blk[w] * h < n ? blk[w] * h : n;
+    const int64_t ld = (blk[w] + 1) * h;
+    int64_t rb = blk[w] * h + t0[w] * kTile, re = blk[w] * h + t1[w] * kTile;
+    if (rb > n) rb = n;
+    if (re > n) re = n;
     c.shard_rb[w] = rb;
-    c.shard_re[w] = rb + h < n ? rb + h : n;
-    c.shard_ld[w] = (blk[w] + 1) * h;
-    const size_t off = w == 0 ? 0 : es * (size_t)(h * (rank + 1) * h);      // low block first, then the high one
+    c.shard_re[w] = re;
+    c.shard_ld[w] = ld;
+    // low block first, then the high one; inside a block the rows of the range start t0 tile rows down
+    const size_t off = es * (size_t)((w == 0 ? 0 : h * (rank + 1) * h) + t0[w] * kTile * ld);
     c.shard_k[w] = nngp_chunk_d ? static_cast<char*>(nngp_chunk_d) + off : nullptr;
     c.shard_t[w] = ntk_chunk_d ? static_cast<char*>(ntk_chunk_d) + off : nullptr;
   }
   return run_build(ctx, c);
+}
+
+extern "C" int smn_kernel_mlp_shard(smn_ctx* ctx, int dtype, int net, int act, int num_hiddens, double w_std,
+                                    double b_std, double last_w_std, const void* x_d, int64_t n, int64_t ldx,
+                                    int64_t d, int nranks, int rank, int64_t block_rows, int get_mask,
+                                    void* nngp_chunk_d, void* ntk_chunk_d) {
+  SMN_TRY(check_common(ctx, dtype, n, 1, d));
+  SMN_ENTER(ctx);
+  const int64_t tpb = block_rows > 0 ? block_rows / kTile : 0;
+  return shard_rows(ctx, dtype, net, act, num_hiddens, w_std, b_std, last_w_std, x_d, n, ldx, d, nranks, rank, block_rows,
+                    0, tpb, 0, tpb, 0, get_mask, nngp_chunk_d, ntk_chunk_d);
+}
+
+extern "C" int smn_kernel_mlp_shard_rows(smn_ctx* ctx, int dtype, int net, int act, int num_hiddens, double w_std,
+                                         double b_std, double last_w_std, const void* x_d, int64_t n, int64_t ldx,
+                                         int64_t d, int nranks, int rank, int64_t block_rows, int64_t lo_t0,
+                                         int64_t lo_t1, int64_t hi_t0, int64_t hi_t1, int reuse_operand, int get_mask,
+                                         void* nngp_chunk_d, void* ntk_chunk_d) {
+  SMN_TRY(check_common(ctx, dtype, n, 1, d));
+  SMN_ENTER(ctx);
+  return shard_rows(ctx, dtype, net, act, num_hiddens, w_std, b_std, last_w_std, x_d, n, ldx, d, nranks, rank, block_rows,
+                    lo_t0, lo_t1, hi_t0, hi_t1, reuse_operand, get_mask, nngp_chunk_d, ntk_chunk_d);
 }
 
 extern "C" int smn_gram(smn_ctx* ctx, int dtype, const void* x1_d, int64_t n1, int64_t ldx1, const void* x2_d,

@@ -94,6 +94,7 @@ def build_lower_sharded(ctx, dtype_code, itemsize, net, act, num_hiddens, w_std,
     the same size) the NTK is built, gathered and -- into ntk_ptr -- unpacked alongside (BASELINE config 5).
     All on the context's stream."""
     import ctypes as C
+    _check_communicator(ctx, world)
     chunk = paired_chunk_elems(n, world)
     h = block_rows(n, world)
     off = rank * chunk * itemsize
@@ -108,3 +109,115 @@ def build_lower_sharded(ctx, dtype_code, itemsize, net, act, num_hiddens, w_std,
         ctx.call("smn_unpack_lower_blocks", dtype_code, stage_ptr, n, world, h, k_ptr, ldk)
     if mine_t is not None and ntk_ptr is not None:
         ctx.call("smn_unpack_lower_blocks", dtype_code, ntk_stage_ptr, n, world, h, ntk_ptr, ldk)
+
+
+def _check_communicator(ctx, world):
+    """A world > 1 exchange on a context without a communicator would quietly degrade to a local copy and hand back a
+    kernel whose other ranks' blocks are garbage: refuse."""
+    import ctypes as C
+    nr, rk = C.c_int(0), C.c_int(0)
+    ctx.call("smn_comm_info", C.byref(nr), C.byref(rk))
+    if nr.value != world:
+        raise RuntimeError("sharded build over %d ranks, but the context's communicator has %d (smn_comm_init first)"
+                           % (world, nr.value))
+
+
+# ------------------------------------------------------------------ pipelined exchange (pieces of the chunks)
+# The all-gather rides behind the build: a rank's chunk is cut into `parts` equal element ranges; as soon as the rank has
+# built the tile rows that complete piece g, piece g of ALL ranks is gathered (and scattered into the factorisation
+# workspace) on the communication stream while the tile rows of piece g+1 are being built.  What remains exposed is the
+# last piece.  Host logic only; the device steps go through a backend object so that the gloo CPU tests drive exactly
+# this control flow.
+
+def default_parts(n: int, world: int) -> int:
+    """Pieces per chunk.  A piece's tile rows are one build launch, and a launch of fewer tiles than the chip has CUs
+    leaves CUs idle for a whole tile time (0.2-0.4 ms at d = 3072): at least ~256 tiles per piece, at most 8 pieces,
+    a power of two that cuts the chunk into multiples of 4 elements."""
+    t = -(-n // TILE)
+    tiles_per_rank = t * (t + 1) // 2 // world
+    p = 8
+    while p > 1 and tiles_per_rank // p < 256:
+        p //= 2
+    chunk = paired_chunk_elems(n, world)
+    while p > 1 and (chunk % p or (chunk // p) % 4):
+        p //= 2
+    return p
+
+
+def part_tile_rows(n: int, world: int, rank: int, parts: int):
+    """For each piece g: (lo_t0, lo_t1, hi_t0, hi_t1) = the 128-row tile rows of the rank's low / high block that must be
+    built before piece g can be gathered and were not built for an earlier piece.  Tile rows are built whole and in
+    packed order (low block top to bottom, then the high block), so piece g needs every tile row that STARTS before the
+    piece ends."""
+    h = block_rows(n, world)
+    chunk = paired_chunk_elems(n, world)
+    if parts <= 0 or chunk % parts or (chunk // parts) % 4:
+        raise ValueError("parts=%d must divide the chunk (%d elements) into multiples of 4" % (parts, chunk))
+    piece = chunk // parts
+    tpb = h // TILE
+    lo, hi = paired_blocks(world, rank)
+    ld_lo, ld_hi = (lo + 1) * h, (hi + 1) * h
+    starts = [t * TILE * ld_lo for t in range(tpb)] + [h * ld_lo + t * TILE * ld_hi for t in range(tpb)]
+    out, built = [], 0
+    for g in range(parts):
+        end = (g + 1) * piece
+        upto = built
+        while upto < 2 * tpb and starts[upto] < end:
+            upto += 1
+        a, b = built, upto                      # packed tile rows [a, b)
+        out.append((min(a, tpb), min(b, tpb), max(a, tpb) - tpb, max(b, tpb) - tpb))
+        built = upto
+    assert built == 2 * tpb
+    return out
+
+
+class DeviceBackend:
+    """The product path: every step is one libsmnngp call on the rank's context."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    def comm_size(self):
+        import ctypes as C
+        nr, rk = C.c_int(0), C.c_int(0)
+        self.ctx.call("smn_comm_info", C.byref(nr), C.byref(rk))
+        return nr.value
+
+    def begin(self, dtype_code, n):
+        self.ctx.call("smn_shard_begin", dtype_code, n)
+
+    def build_rows(self, dtype_code, spec, x_ptr, n, ldx, d, world, rank, h, rows, reuse, mine_ptr):
+        net, act, num_hiddens, w_std, b_std, last_w_std = spec
+        self.ctx.call("smn_kernel_mlp_shard_rows", dtype_code, net, act, num_hiddens, w_std, b_std, last_w_std,
+                      x_ptr, n, ldx, d, world, rank, h, rows[0], rows[1], rows[2], rows[3], 1 if reuse else 0, 1,
+                      mine_ptr, None)
+
+    def exchange_part(self, dtype_code, mine_ptr, stage_ptr, n, world, h, parts, part):
+        self.ctx.call("smn_shard_exchange_part", dtype_code, mine_ptr, stage_ptr, n, world, h, parts, part)
+
+    def lml(self, dtype_code, n, y_ptr, eps_abs, df, scale):
+        import ctypes as C
+        lp, quad, logdet, info = C.c_double(), C.c_double(), C.c_double(), C.c_int()
+        self.ctx.call("smn_lml_from_shards", dtype_code, n, y_ptr, eps_abs, df, scale, C.byref(lp), C.byref(quad),
+                      C.byref(logdet), C.byref(info))
+        return lp.value, quad.value, logdet.value, info.value
+
+
+def lml_sharded_pipelined(backend, dtype_code, spec, x_ptr, n, ldx, d, y_ptr, rank, world, mine_ptr, stage_ptr,
+                          eps_abs, df=0.0, scale=1.0, parts=None):
+    """One SPR.loss evaluation with the kernel build sharded over `world` ranks and the exchange pipelined behind it
+    (`spec` = (net, act, num_hiddens, w_std, b_std, last_w_std); mine: the rank's chunk, paired_chunk_elems elements;
+    stage: world * that).  Returns (logpdf, quad, logdet, info); every rank computes the same values."""
+    if backend.comm_size() != world:
+        raise RuntimeError("sharded build over %d ranks, but the communicator has %d (smn_comm_init first)"
+                           % (world, backend.comm_size()))
+    parts = parts or default_parts(n, world)
+    h = block_rows(n, world)
+    backend.begin(dtype_code, n)
+    padded = False
+    for g, rows in enumerate(part_tile_rows(n, world, rank, parts)):
+        if rows[1] > rows[0] or rows[3] > rows[2]:
+            backend.build_rows(dtype_code, spec, x_ptr, n, ldx, d, world, rank, h, rows, padded, mine_ptr)
+            padded = True
+        backend.exchange_part(dtype_code, mine_ptr, stage_ptr, n, world, h, parts, g)
+    return backend.lml(dtype_code, n, y_ptr, eps_abs, df, scale)

@@ -23,19 +23,59 @@ def test_stdout_carries_only_the_json_line():
     assert "noise from python" in r.stderr and "noise from C stdio" in r.stderr and "late noise" in r.stderr
 
 
-def test_launch_model_counts_the_flops_of_the_lower_triangle():
-    """cholesky_launch_model: trailing + strip updates of the two-level schedule add up to the N^3/3 of the
-    factorisation (plus the appended 128 rows), within the tile granularity."""
+def test_gpus_n_starts_its_own_ranks_before_any_gpu_call(tmp_path):
+    """`python bench.py --gpus 3` with no launcher: the parent imports nothing that touches a GPU and starts three fresh
+    children with RANK / LOCAL_RANK / WORLD_SIZE set and one shared rendezvous file.  Rehearsed with a stand-in for the
+    worker body (this container has no GPU): every child reports its environment, rank 0 publishes the id file the way
+    exchange_rccl_id does, the others read it back."""
     sys.path.insert(0, ROOT)
-    import bench
-    n = 16384
-    trail, n_trail, strip, n_strip = bench.cholesky_launch_model(n + 128, n)
-    total = trail + strip
-    assert 0.95 * n ** 3 / 3 < total < 1.12 * n ** 3 / 3
-    assert n_trail == 64 and n_strip == 64      # 48 near + 16 far updates (the look-ahead splits the far ones again)
+    stub = tmp_path / "fake_bench.py"
+    stub.write_text("\n".join([
+        "import os, sys, json, time",
+        "sys.path.insert(0, %r)" % ROOT,
+        "import bench",
+        "class FakeLib:",
+        "    class _lib:",
+        "        @staticmethod",
+        "        def smn_comm_unique_id(buf):",
+        "            buf.raw = bytes(range(128)); return 0",
+        "if 'RANK' not in os.environ:",
+        "    a = bench.parse(); bench.launch_ranks(a)",
+        "rdv = sys.argv[sys.argv.index('--rendezvous-file') + 1]",
+        "uid = bench.exchange_rccl_id(FakeLib, rdv, int(os.environ['RANK']), timeout_s=30)",
+        "out = dict(rank=os.environ['RANK'], local=os.environ['LOCAL_RANK'], world=os.environ['WORLD_SIZE'], uid=uid.raw.hex())",
+        "open(os.path.join(%r, 'rank%%s.json' %% os.environ['RANK']), 'w').write(json.dumps(out))" % str(tmp_path),
+    ]))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    r = subprocess.run([sys.executable, str(stub), "--gpus", "3", "--steps", "2"], capture_output=True, text=True,
+                       timeout=180, env=env)
+    assert r.returncode == 0, r.stderr
+    got = [json.loads((tmp_path / ("rank%d.json" % i)).read_text()) for i in range(3)]
+    assert [g["rank"] for g in got] == ["0", "1", "2"] and [g["local"] for g in got] == ["0", "1", "2"]
+    assert all(g["world"] == "3" for g in got)
+    assert all(g["uid"] == bytes(range(128)).hex() for g in got)           # the id rank 0 made reached every rank
+
+
+def test_launcher_code_path_imports_no_gpu_module():
+    """The parent of `--gpus N` must not initialise the GPU: nothing above launch_ranks() in main() may import the
+    library (or torch)."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    main = src[src.index("def main():"):]
+    head = main[:main.index("launch_ranks(args)")]
+    assert "import" not in head.replace("# never returns", "")
+    import re
+    top = src[src.index('"""', 10) + 3:src.index("def parse():")]           # the module level below the docstring
+    assert not re.search(r"^\s*(import|from)\s+(torch|smnngp)", top, re.M)
+    assert not re.search(r"^\s*(import|from)\s+torch", src, re.M)            # no torch anywhere in the bench
 
 
 def test_committed_traffic_file_is_the_one_bench_reads():
-    with open(os.path.join(ROOT, "profiles", "r01f_pmc_traffic.json")) as f:
-        t = json.load(f)
-    assert t["traffic_bytes_per_launch"] > 0 and t["launches"] > 0
+    sys.path.insert(0, ROOT)
+    import argparse
+
+    import bench
+    a = argparse.Namespace(config="c4", n=16384, d=3072, layers=4, act="relu", dtype="f32")
+    assert bench.pmc_traffic(a, False) > 0
+    assert bench.pmc_traffic(a, True) is None
+    a.n = 8192
+    assert bench.pmc_traffic(a, False) is None

@@ -1110,3 +1110,74 @@ def test_too_many_output_columns_is_rejected_before_anything_runs(L, ctx):
         ctx.call("smn_spr_predict", L.F64, L.NET_MLP, L.ACT["relu"], 1, 1.0, 0.1, 1.0, x.ptr, 64, 4, x.ptr, 1, 4, 4, y.ptr, 49,
                  1e-3, 0.0, mean.ptr, None, 1, None, None, None)
     assert e.value.code == L.ENOTSUP
+
+
+# ----------------------------------------------------------------------------- pipelined exchange (pieces of the chunks)
+@pytest.mark.parametrize("n,d,world,parts", [(1000, 24, 3, 4), (2048, 16, 2, 8), (700, 10, 1, 2), (1536, 8, 4, 1)])
+def test_pipelined_pieces_assemble_the_same_kernel(L, ctx, n, d, world, parts):
+    """`world` ranks played on one GPU: each builds its chunk piece by piece (smn_kernel_mlp_shard_rows over
+    sharding.part_tile_rows), the pieces are laid out as the part-wise all-gather leaves them ([part][rank][piece]) and
+    scattered with smn_unpack_lower_parts: the lower triangle equals the one-launch kernel bit for bit, and everything
+    the scatter does not own stays untouched (NaN-poisoned target and staging)."""
+    from smnngp import sharding as S
+    rng = np.random.default_rng(90 + n)
+    xh = rng.standard_normal((n, d)).astype(np.float32)
+    x = ctx.to_device(xh)
+    spec = (L.NET_MLP, L.ACT["relu"], 2, 1.3, 0.2, 1.0)
+    h, chunk = S.block_rows(n, world), S.paired_chunk_elems(n, world)
+    piece = chunk // parts
+    stage = ctx.to_device(np.full(world * chunk, np.nan, np.float32))
+    be = S.DeviceBackend(ctx)
+    for r in range(world):
+        mine = ctx.to_device(np.full(chunk, np.nan, np.float32))
+        padded = False
+        for g, rows in enumerate(S.part_tile_rows(n, world, r, parts)):
+            if rows[1] > rows[0] or rows[3] > rows[2]:
+                be.build_rows(L.F32, spec, x.ptr, n, d, d, world, r, h, rows, padded, mine.ptr)
+                padded = True
+            # what the all-gather of piece g does for rank r
+            ctx.call("smn_memcpy_d2d", C.c_void_p(stage.ptr.value + 4 * (g * world + r) * piece),
+                     C.c_void_p(mine.ptr.value + 4 * g * piece), 4 * piece)
+        ctx.synchronize()
+        del mine
+    k = ctx.to_device(np.full((n, n), np.nan, np.float32))
+    ctx.call("smn_unpack_lower_parts", L.F32, stage.ptr, n, world, h, parts, 0, parts, k.ptr, n)
+    ref = ctx.empty((n, n), np.float32)
+    ctx.call("smn_kernel_mlp", L.F32, *spec, x.ptr, n, d, None, 0, 0, d, L.GET_NNGP, L.FILL_LOWER, ref.ptr, None, n)
+    got, want = k.numpy(), ref.numpy()
+    rr, cc = np.indices((n, n))
+    own = cc < np.minimum(n, (rr // 128 + 1) * 128)          # the lower triangle by 128-column tiles
+    assert np.array_equal(got[own], want[own])
+    assert np.isnan(got[~own]).all()
+
+
+def test_pipelined_route_on_a_one_rank_communicator(L, ctx):
+    """smn_shard_begin -> build rows -> smn_shard_exchange_part (RCCL, one rank, on the communication stream) ->
+    smn_lml_from_shards equals the fused smn_spr_loss; a world the communicator does not have is refused."""
+    from smnngp import sharding as S
+    n, d = 1500, 20
+    rng = np.random.default_rng(91)
+    x = ctx.to_device(rng.standard_normal((n, d)).astype(np.float32)); y = ctx.to_device(rng.standard_normal(n).astype(np.float32))
+    spec = (L.NET_MLP, L.ACT["erf"], 3, 1.4, 0.3, 0.9)
+    c2 = L.Context(ctx.device)
+    uid = C.create_string_buffer(128)
+    assert L._lib.smn_comm_unique_id(uid) == 0
+    c2.call("smn_comm_init", 1, 0, uid)
+    x2 = c2.to_device(x.numpy()); y2 = c2.to_device(y.numpy())
+    chunk = S.paired_chunk_elems(n, 1)
+    mine = c2.empty((chunk,), np.float32); stage = c2.empty((chunk,), np.float32)
+    for parts in (1, 2, 4):
+        got = S.lml_sharded_pipelined(S.DeviceBackend(c2), L.F32, spec, x2.ptr, n, d, d, y2.ptr, 0, 1, mine.ptr, stage.ptr,
+                                      1e-2, parts=parts)
+        lp, quad, logdet, info = C.c_double(), C.c_double(), C.c_double(), C.c_int()
+        ctx.call("smn_spr_loss", L.F32, *spec, x.ptr, n, d, d, y.ptr, 1e-2, 0.0, 1.0, C.byref(lp), C.byref(quad),
+                 C.byref(logdet), C.byref(info))
+        assert got[3] == 0 and info.value == 0
+        assert abs(got[0] - lp.value) < 1e-6 * abs(lp.value) and abs(got[2] - logdet.value) < 1e-6 * abs(logdet.value)
+    with pytest.raises(RuntimeError):
+        S.lml_sharded_pipelined(S.DeviceBackend(c2), L.F32, spec, x2.ptr, n, d, d, y2.ptr, 0, 2, mine.ptr, stage.ptr, 1e-2)
+    with pytest.raises(RuntimeError):       # the unpipelined route checks the communicator too
+        S.build_lower_sharded(c2, L.F32, 4, *spec, x2.ptr, n, d, d, 0, 2, stage.ptr, None, 0)
+    c2.call("smn_comm_destroy")
+    del x2, y2, mine, stage
+    c2.close()

@@ -186,3 +186,143 @@ def test_world_size_2_gloo_paired_lower_blocks(n):
     assert np.allclose(k, ref, rtol=1e-12, atol=1e-14)
     ref_lml = O.mvn_logpdf(y, ref + 1e-3 * np.eye(n))
     assert abs(lml - ref_lml) < 1e-9 * abs(ref_lml)
+
+
+# ------------------------------------------------------------------ pipelined exchange: the real driver, a CPU backend
+def test_part_tile_rows_build_every_tile_row_once_before_its_piece_is_gathered():
+    from smnngp import sharding as S
+    for n, w in [(16384, 8), (16384, 2), (32768, 8), (4096, 4), (301, 2), (1000, 3), (128, 8)]:
+        h, chunk, tpb = S.block_rows(n, w), S.paired_chunk_elems(n, w), S.block_rows(n, w) // S.TILE
+        for parts in {1, 2, S.default_parts(n, w)}:
+            piece = chunk // parts
+            for r in range(w):
+                lo, hi = S.paired_blocks(w, r)
+                ld = [(lo + 1) * h, (hi + 1) * h]
+                built = [0, 0]
+                for g, rows in enumerate(S.part_tile_rows(n, w, r, parts)):
+                    assert rows[0] == built[0] and rows[2] == built[1] and rows[1] >= rows[0] and rows[3] >= rows[2]
+                    built = [rows[1], rows[3]]
+                    # every element of pieces <= g lies in a tile row built by now
+                    done = built[0] * S.TILE * ld[0] if built[0] < tpb else h * ld[0] + built[1] * S.TILE * ld[1]
+                    assert done >= min(chunk, (g + 1) * piece)
+                assert built == [tpb, tpb]
+    assert S.default_parts(16384, 8) == 4 and S.default_parts(32768, 8) == 8 and S.default_parts(16384, 1) == 8
+    with pytest.raises(ValueError):
+        S.part_tile_rows(1000, 3, 0, 5)
+
+
+class _CpuBackend:
+    """The device steps of sharding.lml_sharded_pipelined restated on the host: oracle rows for the build, a gloo
+    all-gather per piece, NumPy for the scatter (the mapping of csrc/comm.hip unpack_part_kernel) and the head.  `mine` and
+    `stage` are NumPy arrays handed through the driver untouched."""
+
+    def __init__(self, dist, torch, x, y, world, rank):
+        self.dist, self.torch, self.x, self.y, self.world, self.rank = dist, torch, x, y, world, rank
+        self.calls = []
+
+    def comm_size(self):
+        return self.dist.get_world_size()
+
+    def begin(self, dtype_code, n):
+        self.k = np.full((n, n), np.nan)
+        self.calls.append("begin")
+
+    def build_rows(self, dtype_code, spec, x_ptr, n, ldx, d, world, rank, h, rows, reuse, mine):
+        from oracle import nngp_oracle as O
+        from smnngp import sharding as S
+        _net, act, nh, w_std, b_std, lw = spec
+        lo, hi = S.paired_blocks(world, rank)
+        for blk, t0, t1, base in ((lo, rows[0], rows[1], 0), (hi, rows[2], rows[3], h * (lo + 1) * h)):
+            rb, re = min(n, blk * h + t0 * S.TILE), min(n, blk * h + t1 * S.TILE)
+            if re <= rb:
+                continue
+            ld = (blk + 1) * h
+            kr = O.mlp_kernel(self.x[rb:re], self.x[:re], nh, "relu" if act == 0 else "erf", w_std, b_std, lw)
+            kr[np.arange(re - rb), np.arange(rb, re)] = O.diag_recursion((self.x[rb:re] ** 2).sum(1) / d, nh,
+                                                                         "relu" if act == 0 else "erf", w_std, b_std, lw)
+            for i in range(re - rb):
+                o = base + (rb - blk * h + i) * ld
+                mine[o: o + re] = kr[i]
+        self.calls.append(("build", rows, bool(reuse)))
+
+    def exchange_part(self, dtype_code, mine, stage, n, world, h, parts, part):
+        piece = mine.size // parts
+        recv = self.torch.from_numpy(stage[part * world * piece: (part + 1) * world * piece])
+        self.dist.all_gather_into_tensor(recv, self.torch.from_numpy(mine[part * piece: (part + 1) * piece].copy()))
+        for r in range(world):                                   # unpack_part_kernel, element by element
+            low = h * (r + 1) * h
+            for v in range(piece):
+                e = part * piece + v
+                if e < low:
+                    b, ld, ee = r, (r + 1) * h, e
+                else:
+                    b, ld, ee = 2 * world - 1 - r, (2 * world - r) * h, e - low
+                row, col = b * h + ee // ld, ee % ld
+                if row < n and col < min(n, (row // 128 + 1) * 128):
+                    self.k[row, col] = stage[(part * world + r) * piece + v]
+        self.calls.append(("exchange", part))
+
+    def lml(self, dtype_code, n, y_ptr, eps_abs, df, scale):
+        from oracle import nngp_oracle as O
+        kl = np.tril(self.k)
+        self.ks = kl + np.tril(kl, -1).T
+        lp = O.mvn_logpdf(self.y, self.ks + eps_abs * np.eye(n))
+        return lp, 0.0, 0.0, 0
+
+
+def _pipelined_worker(rank, world, port, n, d, parts, q):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    from smnngp import sharding as S
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(0)
+        x = rng.standard_normal((n, d)); y = rng.standard_normal(n)
+        chunk = S.paired_chunk_elems(n, world)
+        mine = np.full(chunk, np.nan); stage = np.full(world * chunk, np.nan)
+        be = _CpuBackend(dist, torch, x, y, world, rank)
+        spec = (0, 0, 2, 1.2, 0.3, 1.0)
+        lp, _, _, info = S.lml_sharded_pipelined(be, 1, spec, None, n, d, d, None, rank, world, mine, stage, 1e-3, parts=parts)
+        # the driver's order: begin, then for every piece its build (if it adds rows) BEFORE its exchange, pieces in order
+        ex = [c[1] for c in be.calls if c[0] == "exchange"]
+        assert be.calls[0] == "begin" and ex == list(range(parts))
+        reuse = [c[2] for c in be.calls if c[0] == "build"]
+        assert reuse and reuse[0] is False and all(reuse[1:])       # x is padded once
+        try:
+            S.lml_sharded_pipelined(be, 1, spec, None, n, d, d, None, rank, world + 1, mine, stage, 1e-3, parts=parts)
+            raised = False
+        except RuntimeError:
+            raised = True
+        if rank == 0:
+            q.put((be.ks, lp, raised))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,parts", [(300, 4), (513, 8), (200, 1)])
+def test_world_size_2_gloo_pipelined_driver_with_cpu_backend(n, parts):
+    """Two gloo processes run sharding.lml_sharded_pipelined itself -- the function bench.py --gpus N runs on the GPUs --
+    with the device steps replaced by a CPU backend: piece-wise build, piece-wise all-gather, scatter, head."""
+    pytest.importorskip("torch")
+    import torch.multiprocessing as mp
+    from oracle import nngp_oracle as O
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    d = 5
+    procs = [ctx.Process(target=_pipelined_worker, args=(r, 2, port, n, d, parts, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    k, lml, raised = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((n, d)); y = rng.standard_normal(n)
+    ref = O.mlp_kernel(x, None, 2, "relu", 1.2, 0.3, 1.0)
+    assert np.allclose(k, ref, rtol=1e-12, atol=1e-14)
+    ref_lml = O.mvn_logpdf(y, ref + 1e-3 * np.eye(n))
+    assert abs(lml - ref_lml) < 1e-9 * abs(ref_lml)
+    assert raised            # a world the communicator does not have is refused
