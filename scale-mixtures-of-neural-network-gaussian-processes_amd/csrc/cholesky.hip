@@ -27,7 +27,10 @@
 //             of LDS per workgroup, so it needs whole CUs) runs beside F1 on the CUs F1 cannot occupy.
 // (Round 2 tried the alternative -- ONE diagonal workgroup per sub-panel that also inverts L_kk, the rows below as an
 // MFMA GEMM against the inverse, and a windowed left-looking order of the block updates -- and measured it slower at
-// every setting: profiles/r02_notes.md, scratch/r02/potrf_trsm_experiment/.)
+// every setting; and the whole factorisation as ONE persistent launch with tile-granular dependencies (tasks POTRF /
+// TRSM / UPDATE, release / acquire hand-offs between workgroups): correct, 17.2 ms against 16.1 ms at N = 16384, because
+// its critical path -- POTRF + inverse, TRSM tile, diagonal update, three hand-offs per column -- is twice as long as the
+// fused panel's.  profiles/r02_notes.md, scratch/r02/potrf_trsm_experiment/, scratch/r02/dataflow_experiment/.)
 //   trail_kernel   persistent form of the near update (one stream of K-steps per workgroup).
 // Rows [id0, id1) may be declared an identity block (analytic gradients: cholesky_padded's hint): panel and update
 // workgroups whose rows are still structurally zero in the columns at hand leave at once.
