@@ -83,9 +83,22 @@ def launch_ranks(args):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus))
         cmd = [sys.executable, os.path.abspath(sys.argv[0])] + sys.argv[1:] + ["--rendezvous-file", rdv]   # the script as invoked
         procs.append(subprocess.Popen(cmd, env=env, stdout=None if r == 0 else subprocess.DEVNULL))
+    # wait for all of them; if one fails the others would sit in the communicator's rendezvous for ever: end them (by
+    # their own PIDs) and report the failure
     rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
+    alive = list(procs)
+    while alive:
+        for p in list(alive):
+            r = p.poll()
+            if r is None:
+                continue
+            alive.remove(p)
+            if r != 0 and rc == 0:
+                rc = abs(r) or 1
+                for q in alive:
+                    q.terminate()
+        if alive:
+            time.sleep(0.05)
     try:
         for f in os.listdir(tmp):
             os.unlink(os.path.join(tmp, f))

@@ -20,11 +20,39 @@ from . import nngp_oracle as O
 
 
 def host_cores(limit=64):
+    """CPUs this process may really use: the affinity mask, cut by the cgroup CPU quota where one is set (a container that
+    sees 64 cores through its affinity mask but holds a 16-CPU quota runs 64 BLAS threads slower than 16)."""
     try:
         c = len(os.sched_getaffinity(0))
     except AttributeError:
         c = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    c = min(c, max(1, int(int(parts[0]) / int(parts[1]))))
+            else:
+                quota = int(parts[0])
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                    period = int(f.read().split()[0])
+                if quota > 0:
+                    c = min(c, max(1, quota // period))
+            break
+        except (OSError, ValueError, IndexError, ZeroDivisionError):
+            continue
     return max(1, min(c, limit))
+
+
+def blas_threads(n):
+    """Context manager: BLAS / LAPACK thread pools limited to n threads (no-op without threadpoolctl)."""
+    try:
+        from threadpoolctl import threadpool_limits
+        return threadpool_limits(limits=int(n))
+    except Exception:
+        import contextlib
+        return contextlib.nullcontext()
 
 
 def mlp_kernel_rows_threaded(x, num_hiddens, act, w_std, b_std, last_w_std, dtype=np.float64, block=256, cores=None):
@@ -35,7 +63,8 @@ def mlp_kernel_rows_threaded(x, num_hiddens, act, w_std, b_std, last_w_std, dtyp
     n = x.shape[0]
     amap = O.get_act(act)
     t0 = time.perf_counter()
-    k, q, _ = O.input_gram(x, None)
+    with blas_threads(cores):
+        k, q, _ = O.input_gram(x, None)
     q = q.astype(dtype)
 
     def rows(r0):
@@ -54,14 +83,15 @@ def mlp_kernel_rows_threaded(x, num_hiddens, act, w_std, b_std, last_w_std, dtyp
     return k, time.perf_counter() - t0
 
 
-def gaussian_lml(k, y, eps):
+def gaussian_lml(k, y, eps, cores=None):
     """(logpdf, quad, logdet, seconds) of N(y; 0, K + eps I): spax/models.py:96-97, spax/likelihoods.py:25-28.
     K is overwritten by its factor."""
     n = k.shape[0]
     t0 = time.perf_counter()
     k[np.diag_indices(n)] += k.dtype.type(eps)
-    l = sla.cholesky(k, lower=True, overwrite_a=True, check_finite=False)
-    z = sla.solve_triangular(l, np.asarray(y, dtype=k.dtype), lower=True, check_finite=False)
+    with blas_threads(cores or host_cores()):
+        l = sla.cholesky(k, lower=True, overwrite_a=True, check_finite=False)
+        z = sla.solve_triangular(l, np.asarray(y, dtype=k.dtype), lower=True, check_finite=False)
     quad = float(np.dot(z.astype(np.float64), z.astype(np.float64)))
     logdet = 2.0 * float(np.log(np.diag(l).astype(np.float64)).sum())
     lp = -0.5 * quad - 0.5 * n * np.log(2.0 * np.pi) - 0.5 * logdet

@@ -116,3 +116,31 @@ def test_plateau_schedule_follows_the_reference_semantics():
         PlateauSchedule(0.1, mode="down")
     with pytest.raises(ValueError):
         PlateauSchedule(0.1, threshold_mode="pct")
+
+
+def test_clean_tree_build_from_scratch(tmp_path):
+    """`build()` is mtime-incremental and the built objects travel in the working tree, so the everyday build check can
+    pass on stale objects.  This one compiles EVERY source from scratch (force=True, a variant directory of its own, removed
+    afterwards) and checks that the result exports every declared symbol."""
+    import importlib.util
+    import shutil
+    pkg = os.path.join(ROOT, "scale-mixtures-of-neural-network-gaussian-processes_amd")
+    spec = importlib.util.spec_from_file_location("smnngp_build_clean", os.path.join(pkg, "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    objdir = os.path.join(pkg, "build_cleancheck")
+    lib_path = os.path.join(pkg, "libsmnngp_cleancheck.so")
+    shutil.rmtree(objdir, ignore_errors=True)
+    if os.path.exists(lib_path):
+        os.unlink(lib_path)
+    try:
+        out = mod.build(force=True, variant="cleancheck")
+        assert out == lib_path and os.path.exists(lib_path)
+        assert sorted(f for f in os.listdir(objdir) if f.endswith(".o")) == sorted(s.replace(".hip", ".o") for s in mod.SOURCES)
+        raw = ctypes.CDLL(lib_path)
+        for n in declared_symbols():
+            assert hasattr(raw, n), n
+    finally:
+        shutil.rmtree(objdir, ignore_errors=True)
+        if os.path.exists(lib_path):
+            os.unlink(lib_path)

@@ -79,3 +79,23 @@ def test_committed_traffic_file_is_the_one_bench_reads():
     assert bench.pmc_traffic(a, True) is None
     a.n = 8192
     assert bench.pmc_traffic(a, False) is None
+
+
+def test_launcher_ends_the_other_ranks_when_one_fails(tmp_path):
+    """A rank that dies before the rendezvous (no such device, say) must not leave the others waiting in it for ever."""
+    stub = tmp_path / "fake_bench.py"
+    stub.write_text("\n".join([
+        "import os, sys, time",
+        "sys.path.insert(0, %r)" % ROOT,
+        "import bench",
+        "if 'RANK' not in os.environ:",
+        "    bench.launch_ranks(bench.parse())",
+        "if os.environ['RANK'] == '1':",
+        "    sys.exit(7)",
+        "time.sleep(600)",
+    ]))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    import time
+    t0 = time.time()
+    r = subprocess.run([sys.executable, str(stub), "--gpus", "2"], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 7 and time.time() - t0 < 60
