@@ -506,6 +506,21 @@ def main():
             out["exchange_exposed_ms"] = round(per["exposed"][0], 4)
             out["build_plus_assemble_ms"] = round(per["build"][0] + per["prep"][0] + per["exposed"][0], 4)
             out["exchange_parts"] = parts
+            # the same shape's fused lower build on ONE GPU, measured here and now on this rank (one un-sharded step), for the ratio
+            try:
+                ctx.call("smn_profile_enable", 2 << 1)
+                for _ in range(2):
+                    ctx.call("smn_spr_loss", code, L.NET_MLP, act, nl, 1.0, 1e-8, 1.0, x.ptr, n, d, d, y.ptr, eps, 0.0, 1.0,
+                             C.byref(lp), C.byref(quad), C.byref(logdet), C.byref(info))
+                ms1, cnt1 = C.c_double(), C.c_int()
+                ctx.call("smn_profile_read", 1, C.byref(ms1), C.byref(cnt1))
+                ctx.call("smn_profile_enable", 0)
+                one = ms1.value / max(cnt1.value, 1)
+                out["one_gpu_build_ms"] = round(one, 4)
+                out["build_speedup_launches_only"] = round(one / max(per["build"][0], 1e-9), 3)
+                out["build_plus_assemble_speedup"] = round((one + per["prep"][0]) / max(out["build_plus_assemble_ms"], 1e-9), 3)
+            except Exception as e:
+                out["one_gpu_build_error"] = str(e)
         # stand-alone recursion (a3): HBM roofline probe on a stored K0, outside the timed region
         if world == 1 and not sharded and not args.no_recursion_probe:
             try:
