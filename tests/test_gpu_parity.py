@@ -1181,3 +1181,24 @@ def test_pipelined_route_on_a_one_rank_communicator(L, ctx):
     c2.call("smn_comm_destroy")
     del x2, y2, mine, stage
     c2.close()
+
+
+def test_allgather_part_and_comm_info(L, ctx):
+    """smn_allgather_part moves piece g of the chunk to stage[g][rank][piece]; without a communicator (and with a one-rank
+    one) that is a copy; smn_comm_info reports the communicator's size."""
+    nr, rk = C.c_int(-1), C.c_int(-1)
+    ctx.call("smn_comm_info", C.byref(nr), C.byref(rk))
+    assert (nr.value, rk.value) == (1, 0)
+    chunk, parts = 4096, 4
+    piece = chunk // parts
+    src = np.arange(chunk, dtype=np.float32)
+    mine = ctx.to_device(src); stage = ctx.to_device(np.full(chunk, np.nan, np.float32))
+    for g in (2, 0):
+        ctx.call("smn_allgather_part", L.F32, mine.ptr, stage.ptr, chunk, parts, g)
+    got = stage.numpy()
+    assert np.array_equal(got[2 * piece: 3 * piece], src[2 * piece: 3 * piece]) and np.array_equal(got[:piece], src[:piece])
+    assert np.isnan(got[piece: 2 * piece]).all() and np.isnan(got[3 * piece:]).all()
+    with pytest.raises(L.SmnError):
+        ctx.call("smn_allgather_part", L.F32, mine.ptr, stage.ptr, chunk, parts, parts)
+    with pytest.raises(L.SmnError):     # the pipelined exchange without smn_shard_begin
+        ctx.call("smn_shard_exchange_part", L.F32, mine.ptr, stage.ptr, 999, 1, 128, 1, 0)
