@@ -32,7 +32,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32 MFMA (16x16x4 and 32x32x2 forms alike), dense
 PEAK_F64_MFMA_TFLOPS = 78.6    # datasheet; the v_mfma_f64_16x16x4_f64 microbench: profiles/r02_mfma_f64_peak.txt
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s achievable)
 TILE = 128

@@ -35,6 +35,7 @@
 // Rows [id0, id1) may be declared an identity block (analytic gradients: cholesky_padded's hint): panel and update
 // workgroups whose rows are still structurally zero in the columns at hand leave at once.
 #include <climits>
+#include <cstdlib>
 #include <type_traits>
 
 #include "gemm_nt.hpp"
