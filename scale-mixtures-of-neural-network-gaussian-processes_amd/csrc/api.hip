@@ -1,5 +1,15 @@
 // api.hip — context, memory and utility entry points of the C-ABI (include/smnngp.h).
+#include <climits>
+
 #include "internal.hpp"
+
+int smn_allow_lds(smn_ctx* ctx, const void* kernel, size_t lds) {
+  size_t& have = ctx->max_lds[kernel];
+  if (lds <= have) return SMN_OK;
+  SMN_HIP(ctx, hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  have = lds;
+  return SMN_OK;
+}
 
 int smn_workspace(smn_ctx* ctx, int slot, size_t bytes, void** out) {
   if (slot < 0 || slot >= smn_ctx::kSlots) return smn_fail(ctx, SMN_EINVAL, "bad workspace slot");
@@ -87,12 +97,34 @@ __global__ void set_aug_rows_kernel(T* __restrict__ a, int64_t lda, int64_t row0
   a[(row0 + k) * lda + i] = i < n ? y[i * ldy + k] : T(0);
 }
 
+// The three little launches in front of a head's factorisation as one (a reference-sized SPR.loss is launch-bound):
+// the appended right-hand-side rows, the absolute diagonal shift (same arithmetic as diag_shift_kernel) and the reset
+// of the logdet / info scalars.
+template <typename T>
+__global__ void aug_prep_kernel(T* __restrict__ a, int64_t lda, int64_t row0, int64_t ncols, const T* __restrict__ y,
+                                int64_t n, int64_t c, int64_t ldy, int64_t n_shift, double jitter_abs,
+                                double* __restrict__ logdet, int* __restrict__ info) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t k = blockIdx.y;
+  if (i >= ncols || k >= c) return;
+  a[(row0 + k) * lda + i] = i < n ? y[i * ldy + k] : T(0);
+  if (k == 0) {
+    if (i < n_shift) a[i * lda + i] = (T)((double)a[i * lda + i] + jitter_abs);
+    if (i == 0) {
+      *logdet = 0.0;
+      *info = INT_MAX;
+    }
+  }
+}
+
 // mean[ti, k] = -a[aug0 + t + k, aug0 + ti];  cov[ti, tj] = a[aug0 + max, aug0 + min];
-// quad[k] = -a[aug0 + t + k, aug0 + t + k]
+// quad[k] = -a[aug0 + t + k, aug0 + t + k];  with a mailbox (pinned host memory) the thread that owns quad[0] also
+// publishes logdet and info there (what publish_kernel does as a launch of its own).
 template <typename T>
 __global__ void extract_posterior_kernel(const T* __restrict__ a, int64_t lda, int64_t aug0, int64_t t, int64_t c,
                                          T* __restrict__ mean, T* __restrict__ cov, int64_t ldcov,
-                                         double* __restrict__ quad) {
+                                         double* __restrict__ quad, double* __restrict__ mail,
+                                         const double* __restrict__ scal, const int* __restrict__ info) {
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   for (int64_t i = blockIdx.y; i <= t; i += gridDim.y)
   if (i < t) {
@@ -102,7 +134,15 @@ __global__ void extract_posterior_kernel(const T* __restrict__ a, int64_t lda, i
     }
     if (j < c && mean) mean[i * c + j] = -a[(aug0 + t + j) * lda + aug0 + i];
   } else if (i == t) {
-    if (j < c && quad) quad[j] = -(double)a[(aug0 + t + j) * lda + aug0 + t + j];
+    if (j < c && quad) {
+      const double q = -(double)a[(aug0 + t + j) * lda + aug0 + t + j];
+      quad[j] = q;
+      if (mail) mail[2 + j] = q;
+    }
+    if (mail && j == 0) {
+      mail[0] = scal[0];
+      mail[1] = (double)info[0];
+    }
   }
 }
 
@@ -177,12 +217,24 @@ int set_aug_rows(smn_ctx* ctx, int dtype, void* a, int64_t lda, int64_t row0, in
 }
 
 int extract_posterior(smn_ctx* ctx, int dtype, const void* a, int64_t lda, int64_t aug0, int64_t t, int64_t c,
-                      void* mean, void* cov, int64_t ldcov, double* quad_dev) {
-  const int64_t w = t > c ? t : c;
+                      void* mean, void* cov, int64_t ldcov, double* quad_dev, bool publish) {
+  const int64_t w = (t > c ? t : c) > 1 ? (t > c ? t : c) : 1;
   dim3 g((unsigned)((w + 255) / 256), (unsigned)(t + 1 < 32768 ? t + 1 : 32768));
+  double* mail = publish ? ctx->d_mail : nullptr;
   DISPATCH_T(dtype,
-             hipLaunchKernelGGL(extract_posterior_kernel<float>, g, dim3(256), 0, ctx->stream, static_cast<const float*>(a), lda, aug0, t, c, static_cast<float*>(mean), static_cast<float*>(cov), ldcov, quad_dev),
-             hipLaunchKernelGGL(extract_posterior_kernel<double>, g, dim3(256), 0, ctx->stream, static_cast<const double*>(a), lda, aug0, t, c, static_cast<double*>(mean), static_cast<double*>(cov), ldcov, quad_dev));
+             hipLaunchKernelGGL(extract_posterior_kernel<float>, g, dim3(256), 0, ctx->stream, static_cast<const float*>(a), lda, aug0, t, c, static_cast<float*>(mean), static_cast<float*>(cov), ldcov, quad_dev, mail, ctx->d_scal, ctx->d_info),
+             hipLaunchKernelGGL(extract_posterior_kernel<double>, g, dim3(256), 0, ctx->stream, static_cast<const double*>(a), lda, aug0, t, c, static_cast<double*>(mean), static_cast<double*>(cov), ldcov, quad_dev, mail, ctx->d_scal, ctx->d_info));
+  SMN_CHECK_LAUNCH(ctx);
+  return SMN_OK;
+}
+
+int aug_prep(smn_ctx* ctx, int dtype, void* a, int64_t lda, int64_t row0, int64_t ncols, const void* y, int64_t n,
+             int64_t c, int64_t ldy, int64_t n_shift, double jitter_abs) {
+  if (c <= 0 || n_shift > ncols) return smn_fail(ctx, SMN_EINVAL, "aug_prep: bad sizes");
+  dim3 g((unsigned)((ncols + 255) / 256), (unsigned)c);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(aug_prep_kernel<float>, g, dim3(256), 0, ctx->stream, static_cast<float*>(a), lda, row0, ncols, static_cast<const float*>(y), n, c, ldy, n_shift, jitter_abs, ctx->d_scal, ctx->d_info),
+             hipLaunchKernelGGL(aug_prep_kernel<double>, g, dim3(256), 0, ctx->stream, static_cast<double*>(a), lda, row0, ncols, static_cast<const double*>(y), n, c, ldy, n_shift, jitter_abs, ctx->d_scal, ctx->d_info));
   SMN_CHECK_LAUNCH(ctx);
   return SMN_OK;
 }

@@ -759,8 +759,8 @@ int cholesky_t(smn_ctx* ctx, T* a, int64_t n_total, int64_t n_factor, int64_t ld
   void* side = nullptr;   // factored diagonal blocks, [n_factor/128][128*128]
   SMN_TRY(smn_workspace(ctx, 3, sizeof(T) * (size_t)n_factor * PB, &side));
   hipStream_t st = ctx->stream;
-  hipLaunchKernelGGL(init_scalars_kernel, dim3(1), dim3(1), 0, st, ctx->d_scal, ctx->d_info);
-  if (n_shift > 0 && (jitter_abs != 0.0 || ridge_rel != 0.0)) {
+  if (!ctx->chol_prepped) hipLaunchKernelGGL(init_scalars_kernel, dim3(1), dim3(1), 0, st, ctx->d_scal, ctx->d_info);
+  if (!ctx->chol_prepped && n_shift > 0 && (jitter_abs != 0.0 || ridge_rel != 0.0)) {
     if (ridge_rel != 0.0)
       hipLaunchKernelGGL(diag_trace_kernel<T>, dim3(1), dim3(256), 0, st, a, lda, n_shift, ctx->d_scal + 1);
     hipLaunchKernelGGL(diag_shift_kernel<T>, dim3((unsigned)((n_shift + 255) / 256)), dim3(256), 0, st, a, lda,
@@ -916,6 +916,18 @@ int fetch_results(smn_ctx* ctx, const double* quad_dev, int nq, double* quad_h, 
   hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->d_scal, ctx->d_info, quad_dev, nq,
                      ctx->d_mail);
   SMN_CHECK_LAUNCH(ctx);
+  SMN_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const volatile double* m = ctx->h_mail;
+  int inf = (int)m[1];
+  if (inf == INT_MAX) inf = 0;
+  if (logdet) *logdet = m[0];
+  if (info) *info = inf;
+  for (int i = 0; i < nq && quad_h; ++i) quad_h[i] = m[2 + i];
+  return SMN_OK;
+}
+
+int fetch_mail(smn_ctx* ctx, int nq, double* quad_h, double* logdet, int* info) {
+  if (nq < 0 || nq > 62) return smn_fail(ctx, SMN_EINVAL, "fetch_mail: %d values", nq);
   SMN_HIP(ctx, hipStreamSynchronize(ctx->stream));
   const volatile double* m = ctx->h_mail;
   int inf = (int)m[1];

@@ -394,7 +394,7 @@ __global__ void __launch_bounds__(256, SMN_CNN32_OCC) conv_pair32_kernel(PairArg
 template <typename T, typename K>
 int launch_pair_form(smn_ctx* ctx, K kern, PairArgs<T> a, int64_t blocks, size_t lds) {
   if (lds > 0)
-    SMN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    SMN_TRY(smn_allow_lds(ctx, reinterpret_cast<const void*>(kern), lds));
   int per_cu = 0;
   if (ctx->cnn_tiled > 0 && hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, lds) == hipSuccess &&
       per_cu > 0) {
@@ -450,7 +450,7 @@ int cnn_t(smn_ctx* ctx, int act, int layers, double w, double b, double lw, cons
   T* d2 = d1 + n1;
   {
     ProfScope ps(ctx, PROF_PREP, ctx->stream);
-    SMN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_q_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q));
+    SMN_TRY(smn_allow_lds(ctx, reinterpret_cast<const void*>(conv_q_kernel<T>), lds_q));
     hipLaunchKernelGGL(conv_q_kernel<T>, dim3((unsigned)n1), dim3(256), lds_q, ctx->stream,
                        static_cast<const T*>(x1), n1, p, R1, d1);
     if (!sym)

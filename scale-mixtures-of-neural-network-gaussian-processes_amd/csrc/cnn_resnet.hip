@@ -345,7 +345,7 @@ int resnet_t(smn_ctx* ctx, int act, int block_size, double w, double b, double l
   T* d2 = d1 + n1;
   {
     ProfScope ps(ctx, PROF_PREP, ctx->stream);
-    SMN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(resnet_q_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q));
+    SMN_TRY(smn_allow_lds(ctx, reinterpret_cast<const void*>(resnet_q_kernel<T>), lds_q));
     hipLaunchKernelGGL(resnet_q_kernel<T>, dim3((unsigned)n1), dim3(256), lds_q, ctx->stream, static_cast<const T*>(x1), p, R1, d1);
     if (!sym)
       hipLaunchKernelGGL(resnet_q_kernel<T>, dim3((unsigned)n2), dim3(256), lds_q, ctx->stream, static_cast<const T*>(x2), p, R2, d2);
@@ -362,10 +362,10 @@ int resnet_t(smn_ctx* ctx, int act, int block_size, double w, double b, double l
   {
     ProfScope ps(ctx, PROF_BUILD, ctx->stream);
     if (act == SMN_ACT_RELU) {
-      SMN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(resnet_pair_kernel<T, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p));
+      SMN_TRY(smn_allow_lds(ctx, reinterpret_cast<const void*>(resnet_pair_kernel<T, 0>), lds_p));
       hipLaunchKernelGGL((resnet_pair_kernel<T, 0>), dim3((unsigned)blocks), dim3(256), lds_p, ctx->stream, a);
     } else {
-      SMN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(resnet_pair_kernel<T, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p));
+      SMN_TRY(smn_allow_lds(ctx, reinterpret_cast<const void*>(resnet_pair_kernel<T, 1>), lds_p));
       hipLaunchKernelGGL((resnet_pair_kernel<T, 1>), dim3((unsigned)blocks), dim3(256), lds_p, ctx->stream, a);
     }
   }

@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/smnngp.h"
@@ -50,6 +51,8 @@ struct smn_ctx {
   // structural-zero hint for the factorisation in flight: appended rows [id0, id1) hold an identity block
   // (row id0 + i is zero left of column i), set by cholesky_padded, -1 = none
   int64_t chol_id0 = -1, chol_id1 = -1;
+  bool chol_prepped = false;         // the caller has shifted the diagonal and reset logdet / info already (aug_prep)
+  std::unordered_map<const void*, size_t> max_lds;   // largest dynamic-LDS size already allowed per kernel (smn_allow_lds)
   bool lds_attrs_done[2] = {false, false};   // hipFuncSetAttribute(MaxDynamicSharedMemorySize) issued for f32 / f64 kernels
   int panel_small_rows = 4096;       // f32 panels with at most this many rows below use 64-row workgroups (env SMN_PANEL_SMALL)
   int quarter_tile_max = 256;        // update launches with at most this many 128x128 tiles use 64x64 tiles (env SMN_QUARTER_TILES)
@@ -137,5 +140,8 @@ inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
 // workspace slot `slot` of at least `bytes` bytes (contents undefined)
 int smn_workspace(smn_ctx* ctx, int slot, size_t bytes, void** out);
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per kernel and context (it costs ~20 us of host time per call: a
+// reference-sized SPR.loss is 13 launches and 130 us in all).
+int smn_allow_lds(smn_ctx* ctx, const void* kernel, size_t lds);
 
 inline size_t dtype_size(int dtype) { return dtype == SMN_F64 ? 8 : 4; }

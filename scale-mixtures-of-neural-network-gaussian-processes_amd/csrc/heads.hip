@@ -77,15 +77,23 @@ int aug_finish(smn_ctx* ctx, int dtype, const Aug& g, const void* y, int64_t ldy
                double ridge_rel, void* mean, void* cov, int64_t ldcov, double* quad_h, double* logdet_h, int* info_h,
                bool td_identity = false) {
   if (g.c > 48) return smn_fail(ctx, SMN_ENOTSUP, "more than 48 output columns");   // the mailbox holds 62 doubles
-  SMN_TRY(set_aug_rows(ctx, dtype, g.a, g.lda, g.n_pad + g.t, g.n_total, y, g.n, g.c, ldy));
+  // with an absolute jitter only, the right-hand-side rows, the diagonal shift and the scalar reset are one launch
+  const bool prepped = ridge_rel == 0.0 && g.c > 0;
+  if (prepped)
+    SMN_TRY(aug_prep(ctx, dtype, g.a, g.lda, g.n_pad + g.t, g.n_total, y, g.n, g.c, ldy, jitter_abs != 0.0 ? n_shift : 0, jitter_abs));
+  else
+    SMN_TRY(set_aug_rows(ctx, dtype, g.a, g.lda, g.n_pad + g.t, g.n_total, y, g.n, g.c, ldy));
   // identity test rows: whole 128-row tiles of them may be skipped where they are structurally zero
   const int64_t id0 = td_identity ? g.n_pad : -1, id1 = td_identity ? g.n_pad + g.t / kTile * kTile : -1;
-  SMN_TRY(cholesky_padded(ctx, dtype, g.a, g.n_total, g.n_pad, g.lda, n_shift, jitter_abs, ridge_rel, false, id0, id1));
+  ctx->chol_prepped = prepped;
+  const int crc = cholesky_padded(ctx, dtype, g.a, g.n_total, g.n_pad, g.lda, n_shift, jitter_abs, ridge_rel, false, id0, id1);
+  ctx->chol_prepped = false;
+  SMN_TRY(crc);
   double* quad_dev = ctx->d_scal + 8;
-  SMN_TRY(extract_posterior(ctx, dtype, g.a, g.lda, g.n_pad, g.t, g.c, mean, cov, ldcov, quad_dev));
+  SMN_TRY(extract_posterior(ctx, dtype, g.a, g.lda, g.n_pad, g.t, g.c, mean, cov, ldcov, quad_dev, true));
   double ld = 0.0;
   int info = 0;
-  SMN_TRY(fetch_results(ctx, quad_dev, quad_h ? (int)g.c : 0, quad_h, &ld, &info));
+  SMN_TRY(fetch_mail(ctx, quad_h ? (int)g.c : 0, quad_h, &ld, &info));
   if (info != 0) {
     ld = std::nan("");
     if (quad_h)

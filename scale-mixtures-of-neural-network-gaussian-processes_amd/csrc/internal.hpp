@@ -64,7 +64,13 @@ int set_aug_rows(smn_ctx* ctx, int dtype, void* a, int64_t lda, int64_t row0, in
                  int64_t n, int64_t c, int64_t ldy);
 // predictive read-out of a factored augmented matrix (see heads.hip)
 int extract_posterior(smn_ctx* ctx, int dtype, const void* a, int64_t lda, int64_t aug0, int64_t t, int64_t c,
-                      void* mean, void* cov, int64_t ldcov, double* quad_dev);
+                      void* mean, void* cov, int64_t ldcov, double* quad_dev, bool publish = false);
+// set_aug_rows + absolute diagonal shift + reset of logdet / info in one launch (cholesky_padded then runs with
+// ctx->chol_prepped set and skips its own two)
+int aug_prep(smn_ctx* ctx, int dtype, void* a, int64_t lda, int64_t row0, int64_t ncols, const void* y, int64_t n,
+             int64_t c, int64_t ldy, int64_t n_shift, double jitter_abs);
+// the mailbox after a launch that published into it (extract_posterior(..., publish = true)): synchronise and read
+int fetch_mail(smn_ctx* ctx, int nq, double* quad_h, double* logdet, int* info);
 int solve_rows_padded(smn_ctx* ctx, int dtype, void* a, int64_t n_total, int64_t n_factor, int64_t lda);
 int transpose_matrix(smn_ctx* ctx, int dtype, void* dst, int64_t ldd, const void* src, int64_t lds,
                      int64_t rows, int64_t cols);   // dst[c, r] = src[r, c]

@@ -544,12 +544,7 @@ void set_fast(LayerProg* p, bool ntk) {
 template <typename T, int NET, int ACT, bool NTK>
 int launch_build_t(smn_ctx* ctx, const BuildArgs<T>& a, int64_t ntiles, size_t lds) {
   auto kern = build_kernel<T, NET, ACT, NTK>;
-  if (const char* e = getenv("SMN_DEBUG_LDS")) {   // occupancy experiments only: inflate the LDS request
-    const size_t want = (size_t)atol(e);
-    if (want > lds && want <= 160 * 1024) lds = want;
-  }
-  SMN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  SMN_TRY(smn_allow_lds(ctx, reinterpret_cast<const void*>(kern), lds));
   {
     ProfScope ps(ctx, PROF_BUILD, ctx->stream);
     hipLaunchKernelGGL(kern, dim3((unsigned)ntiles), dim3(256), lds, ctx->stream, a);
@@ -651,7 +646,7 @@ template <typename T, int NET, int ACT, bool NTK>
 int launch_rec_t(smn_ctx* ctx, const RecArgs<T>& a, dim3 grid, size_t lds) {
   if (a.sym_tiles) {
     auto kern = recursion_sym_kernel<T, NET, ACT, NTK>;
-    SMN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    SMN_TRY(smn_allow_lds(ctx, reinterpret_cast<const void*>(kern), lds));
     {
       ProfScope ps(ctx, PROF_RECURSION, ctx->stream);
       hipLaunchKernelGGL(kern, grid, dim3(256), lds, ctx->stream, a);
