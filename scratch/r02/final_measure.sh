@@ -5,6 +5,7 @@ set -u
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r02_final
 mkdir -p $O
+rm -rf $O/stats
 cd $R
 timeout -k 10 900 python3 -m pytest tests -x -q -m gpu > $O/gpu_tests.log 2>&1
 echo "pytest rc=$?"; tail -4 $O/gpu_tests.log

@@ -586,6 +586,8 @@ def test_cholesky_more_workgroups_than_cus_and_lookahead(L, ctx, dtype, n, m):
     {"SMN_QUARTER_TILES": "0"},                                # no 64x64 tiles for the smallest launches
     {"SMN_QUARTER_TILES": "100000"},                           # 64x64 tiles everywhere
     {"SMN_PANEL_SMALL": "0"},                                  # 128-row panel workgroups throughout
+    {"SMN_PANEL_HELPERS": "0"},                                # block updates inside the row waves (panel_kernel)
+    {"SMN_PANEL_HELPERS": "0", "SMN_PANEL_SMALL": "0"},
 ])
 def test_cholesky_schedule_variants_agree(L, env):
     """Every schedule the environment switches select factors the same matrix to the same result (the default
@@ -618,6 +620,37 @@ def test_cholesky_schedule_variants_agree(L, env):
     assert i0 == 0 and i1 == 0 and abs(ld1 - ld0) < 1e-5 * abs(ld0)
     il = np.tril_indices(n + m)
     assert relerr_norm(f1[il], f0[il]) < 1e-4
+
+
+@pytest.mark.parametrize("dtype,n,m", [(np.float32, 2048, 128), (np.float32, 4352, 0), (np.float64, 1152, 128)])
+def test_panel_helper_waves_give_the_same_bits(L, dtype, n, m):
+    """panelh_kernel moves the panel's MFMA block updates onto a second set of waves that runs one 16-column block ahead;
+    every accumulator still sees the same K order, so the factor must equal panel_kernel's bit for bit (a hand-off between
+    the helper waves and the row threads that came too early or too late would show here).  Sizes on both sides of the
+    64-row / 128-row switch (SMN_PANEL_SMALL = 4096 rows)."""
+    import os
+    rng = np.random.default_rng(21)
+    g = rng.standard_normal((n + m, 64)).astype(dtype)
+    a = (g @ g.T / 64 + np.diag(rng.uniform(1.0, 2.0, n + m))).astype(dtype)
+    out = []
+    for helpers in ("0", "1"):
+        old = os.environ.get("SMN_PANEL_HELPERS")
+        os.environ["SMN_PANEL_HELPERS"] = helpers
+        try:
+            c = L.Context(0)
+        finally:
+            if old is None:
+                del os.environ["SMN_PANEL_HELPERS"]
+            else:
+                os.environ["SMN_PANEL_HELPERS"] = old
+        ad = c.to_device(a)
+        info, logdet = C.c_int(), C.c_double()
+        c.call("smn_cholesky", L.dtype_code(dtype), ad.ptr, n + m, n, n + m, 0, 0.0, 0.0, C.byref(info), C.byref(logdet))
+        assert info.value == 0
+        out.append((logdet.value, ad.numpy()))
+    il = np.tril_indices(n + m)
+    assert out[0][0] == out[1][0]
+    assert np.array_equal(out[0][1][il], out[1][1][il])
 
 
 @pytest.mark.parametrize("dtype,n,m", [(np.float32, 9216, 128), (np.float64, 8192, 0)])
