@@ -287,6 +287,7 @@ extern "C" int smn_ctx_create(int device_id, smn_ctx** out) {
   const bool main_ok = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_hi) == hipSuccess;
   if (const char* e = getenv("SMN_CHAIN_CUS")) c->chain_cus = atoi(e);
   if (const char* e = getenv("SMN_CHAIN_MIN_N")) c->chain_min_n = atol(e);
+  if (const char* e = getenv("SMN_F0_FIRST_TILES")) c->f0_first_tiles = atol(e);
   if (c->chain_cus > 0 && c->chain_cus < c->num_cu) {
     if (!masked_stream(&c->stream_bulk, c->chain_cus, c->num_cu)) c->stream_bulk = nullptr;   // no look-ahead then
   }

@@ -1067,11 +1067,21 @@ int cholesky_t(smn_ctx* ctx, T* a, int64_t n_total, int64_t n_factor, int64_t ld
         continue;
       }
       const int64_t s_next = s_end >= n_factor ? s_end : ((n_factor - s_end < S) ? n_factor : s_end + S);
-      SMN_HIP(ctx, hipEventRecord(ctx->ev_a, st));
-      SMN_HIP(ctx, hipStreamWaitEvent(sb, ctx->ev_a, 0));
+      // Once F1 is small (the chain-bound tail) it starts BEHIND F0 instead of beside it: F0 is on the chain's critical path
+      // and, sharing the chip with an F1 that nobody waits for, takes three times as long (profiles/r02_tail_chain_timeline.txt).
+      const int64_t tm1 = n_total > s_next ? (n_total - s_next) / kTile : 0;
+      const bool f0_first = tm1 * (tm1 + 1) / 2 <= ctx->f0_first_tiles;
+      if (!f0_first) {
+        SMN_HIP(ctx, hipEventRecord(ctx->ev_a, st));
+        SMN_HIP(ctx, hipStreamWaitEvent(sb, ctx->ev_a, 0));
+      }
       if (bulk_busy) SMN_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_b, 0));
       if (s_next > s_end)   // F0
         SMN_TRY(launch_update<T>(ctx, st, a, lda, s_end, s_end, s0, K, (n_total - s_end) / kTile, (s_next - s_end) / kTile, 2));
+      if (f0_first) {
+        SMN_HIP(ctx, hipEventRecord(ctx->ev_a, st));
+        SMN_HIP(ctx, hipStreamWaitEvent(sb, ctx->ev_a, 0));
+      }
       if (n_total > s_next) {   // F1
         const int64_t tm = (n_total - s_next) / kTile;
         bulk_busy = true;       // set first: an error below must still join the bulk stream

@@ -20,6 +20,7 @@ struct smn_ctx {
   hipStream_t stream_bulk = nullptr;  // CU-masked stream of the far updates F1: may not use the first chain_cus CUs
   int chain_cus = 32;                 // CUs kept free for the panel chain (env SMN_CHAIN_CUS; 0 = no look-ahead)
   int64_t chain_min_n = 8192;         // look-ahead only from this matrix size on (env SMN_CHAIN_MIN_N)
+  int64_t f0_first_tiles = 2000;      // F1 launches of at most this many tiles start behind F0, not beside it (env SMN_F0_FIRST_TILES; 0: never)
   hipStream_t stream_comm = nullptr;  // the pipelined exchange: all-gather + scatter of one piece while the next one is being built
   hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
   hipEvent_t ev_c0 = nullptr, ev_c1 = nullptr;   // main -> comm (piece built), comm -> main (all pieces scattered)
