@@ -64,7 +64,7 @@ struct smn_ctx {
   int cnn_tiled = 1;                 // conv-NNGP pair kernel: XCD-tiled pair order for large problems (env SMN_CNN_TILED: 0 never, 2 always)
   bool rec_sym = true;               // stand-alone recursion: lower-tile + mirror kernel when symmetric (env SMN_REC_SYM=0)
   bool persistent_trail = true;      // persistent trailing-update kernel (env SMN_PERSISTENT=0 disables)
-  bool xcd_map = false;              // XCD-aware patch tile order (env SMN_XCD_MAP=1)
+  bool xcd_map = true;               // XCD-aware patch tile order of launches of 512 tiles and more (env SMN_XCD_MAP=0: linear order)
 };
 
 enum { PROF_PREP = 0, PROF_BUILD = 1, PROF_RECURSION = 2, PROF_PANEL = 3, PROF_STRIP = 4, PROF_TRAIL = 5,
