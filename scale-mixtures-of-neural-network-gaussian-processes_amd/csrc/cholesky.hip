@@ -1038,6 +1038,8 @@ int cholesky_t(smn_ctx* ctx, T* a, int64_t n_total, int64_t n_factor, int64_t ld
   constexpr int64_t W = 2 * PB;
   int64_t S = ctx->super_panel / W * W;
   if (S < W) S = W;
+  int64_t Swide = ctx->super_panel_wide / W * W;
+  if (Swide < S) Swide = S;
   hipStream_t sb = (n_total >= ctx->chain_min_n && ctx->stream_bulk) ? ctx->stream_bulk : nullptr;
   bool bulk_busy = false;
   int rc = SMN_OK;
@@ -1046,8 +1048,13 @@ int cholesky_t(smn_ctx* ctx, T* a, int64_t n_total, int64_t n_factor, int64_t ld
       rc = smn_fail(ctx, SMN_EHIP, "cholesky: %s", hipGetErrorString(e));
   };
   auto body = [&]() -> int {
-    for (int64_t s0 = 0; s0 < n_factor; s0 += S) {
-      const int64_t s_end = (n_factor - s0 < S) ? n_factor : s0 + S;
+    // Super-panels are wider while many rows are left (the update-bound phase: a K = 2048 far update runs closer to the
+    // tile engine's rate and halves the launches and their tails) and S wide in the chain-bound rest.
+    auto width = [&](int64_t c0) { return (sb && n_total - c0 >= ctx->super_wide_rows) ? Swide : S; };
+    for (int64_t s0 = 0, s_stop = 0; s0 < n_factor; s0 = s_stop) {
+      const int64_t Sc = width(s0);
+      const int64_t s_end = (n_factor - s0 < Sc) ? n_factor : s0 + Sc;
+      s_stop = s_end;
       for (int64_t j0 = s0; j0 < s_end; j0 += W) {
         const int64_t w = (s_end - j0 < W) ? s_end - j0 : W;
         for (int64_t js = j0; js < j0 + w; js += PB) {
@@ -1066,7 +1073,8 @@ int cholesky_t(smn_ctx* ctx, T* a, int64_t n_total, int64_t n_factor, int64_t ld
         SMN_TRY(launch_update<T>(ctx, st, a, lda, s_end, s_end, s0, K, tm, tm, 1));
         continue;
       }
-      const int64_t s_next = s_end >= n_factor ? s_end : ((n_factor - s_end < S) ? n_factor : s_end + S);
+      const int64_t Sn = width(s_end);   // the next super-panel's width decides where F0 ends and F1 begins
+      const int64_t s_next = s_end >= n_factor ? s_end : ((n_factor - s_end < Sn) ? n_factor : s_end + Sn);
       // Once F1 is small (the chain-bound tail) it starts BEHIND F0 instead of beside it: F0 is on the chain's critical path
       // and, sharing the chip with an F1 that nobody waits for, takes three times as long (profiles/r02_tail_chain_timeline.txt).
       const int64_t tm1 = n_total > s_next ? (n_total - s_next) / kTile : 0;

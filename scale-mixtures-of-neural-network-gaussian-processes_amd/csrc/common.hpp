@@ -49,6 +49,8 @@ struct smn_ctx {
   double prof_flops[10] = {};         // MFMA flops EXECUTED per category since smn_profile_enable (whole tiles; host-side count)
   int num_cu = 256;                  // hipDeviceProp_t::multiProcessorCount
   int64_t super_panel = 1024;        // columns per super-panel of the two-level Cholesky (env SMN_SUPER)
+  int64_t super_panel_wide = 2048;   // ... while at least super_wide_rows rows are left (env SMN_SUPER_WIDE, SMN_SUPER_WIDE_ROWS)
+  int64_t super_wide_rows = 18432;   // (measured: wide pays from ~18k rows left on, profiles/r02_wide_super_panel_sweep.txt; 0 rows = always wide)
   // structural-zero hint for the factorisation in flight: appended rows [id0, id1) hold an identity block
   // (row id0 + i is zero left of column i), set by cholesky_padded, -1 = none
   int64_t chol_id0 = -1, chol_id1 = -1;

@@ -586,6 +586,8 @@ def test_cholesky_more_workgroups_than_cus_and_lookahead(L, ctx, dtype, n, m):
     {"SMN_QUARTER_TILES": "0"},                                # no 64x64 tiles for the smallest launches
     {"SMN_QUARTER_TILES": "100000"},                           # 64x64 tiles everywhere
     {"SMN_PANEL_SMALL": "0"},                                  # 128-row panel workgroups throughout
+    {"SMN_SUPER_WIDE_ROWS": "4096"},                           # 2048-column super-panels while 4096 rows are left, 1024 below
+    {"SMN_SUPER_WIDE_ROWS": "0", "SMN_SUPER_WIDE": "3072"},    # 3072-column super-panels throughout
     {"SMN_F0_FIRST_TILES": "0"},                               # F1 always beside F0
     {"SMN_F0_FIRST_TILES": "100000"},                          # F1 always behind F0
     {"SMN_PANEL_HELPERS": "0"},                                # block updates inside the row waves (panel_kernel)
