@@ -31,7 +31,7 @@ def build(force=False, verbose=False, variant="", defines=()):
     objdir = os.path.join(HERE, "build" + suffix)
     lib = os.path.join(HERE, "libsmnngp%s.so" % suffix)
     os.makedirs(objdir, exist_ok=True)
-    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".inc"))]
     headers.append(os.path.join(HERE, "..", "include", "smnngp.h"))
     jobs = []
     for s in SOURCES:

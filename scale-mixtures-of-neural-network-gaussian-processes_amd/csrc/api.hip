@@ -270,7 +270,7 @@ extern "C" int smn_ctx_create(int device_id, smn_ctx** out) {
   if (const char* e = getenv("SMN_SUPER_WIDE")) c->super_panel_wide = atol(e);
   if (const char* e = getenv("SMN_SUPER_WIDE_ROWS")) c->super_wide_rows = atol(e);
   if (const char* e = getenv("SMN_PANEL_SMALL")) c->panel_small_rows = atoi(e);
-  if (const char* e = getenv("SMN_PANEL_HELPERS")) c->panel_helpers = atoi(e) != 0;
+  if (const char* e = getenv("SMN_PANEL_HELPERS")) c->panel_helpers = atoi(e);
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0)

@@ -43,6 +43,7 @@
 
 #include "gemm_nt.hpp"
 #include "internal.hpp"
+#include "panel_leaf.hpp"
 
 namespace {
 
@@ -592,6 +593,232 @@ __global__ void __launch_bounds__(2 * panel_threads(XRV)) panelh_kernel(T* __res
   }
 }
 
+// panelr_kernel — the form the factorisation launches from round 3 on: the 8-column in-LDS micro-panels are replaced by
+// a register-resident 16x16 leaf (panel_leaf.hpp).
+//   Row threads (waves [0, NW), one LDS row each): per 16-column block, load the lane's own 16 entries and a copy of
+//   diagonal-tile row (lane & 15), run the leaf (factor + TRSM of the own row through DPP row_newbcast: no LDS traffic,
+//   no barrier inside the block), write the solved entries back to the LDS image AND straight to global memory (the
+//   appended rows' columns of this block are final: nothing is left to store when the last block is done).
+//   Helper waves ([NW, 2 NW)): stream the raw columns of the blocks to come from global memory into LDS three blocks
+//   ahead of their use (the row threads take block 0 straight into registers, so the first leaf starts after ONE
+//   global round trip instead of after the whole 128 KB image has landed), and bring the next block's columns up to
+//   date with MFMAs exactly as in panelh_kernel: K = [0, cb) beside the leaf, the block just finished behind it.
+// Two workgroup barriers per block (leaf done / next block up to date) instead of panelh_kernel's five.
+// Cost (profiles/r03_*): one wave issues a vector instruction every ~6.5 cycles, so the leaf's 288 are ~0.85 us of the
+// ~1.2 us a block takes; the sub-panel is ~11 us against 27.
+template <typename T, int XRV = PanelCfg<T>::XR>
+__global__ void __launch_bounds__(2 * panel_threads(XRV)) panelr_kernel(T* __restrict__ a, int64_t lda, int64_t j0,
+                                                                          int64_t rbeg, int64_t n_total,
+                                                                          double* __restrict__ logdet,
+                                                                          int* __restrict__ info, T* __restrict__ ldiag_out,
+                                                                          int64_t id0, int64_t id1) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int XR = XRV, NTV = panel_threads(XRV), LD = PanelCfg<T>::LD;
+  constexpr int VEC = 16 / sizeof(T);
+  constexpr int CB = 16, NB = PB / CB, VPC = CB / VEC, ROWS = PB + XR;
+  using vec_t = typename Mfma<T>::vec_t;
+  using M = PanelMma<T>;
+  constexpr int NW = NTV / 64;
+  constexpr int RT = ROWS / M::TM;
+  constexpr int TPW = (RT + NW - 1) / NW;
+  static_assert(RT % NW == 0 && TPW <= 4, "tile split over the helper waves");
+  static_assert((ROWS * VPC) % NTV == 0, "chunk vectors split evenly over the helper threads");
+  T* S = reinterpret_cast<T*>(smem);        // [PB + XR][LD]
+  const int tid = threadIdx.x;
+  const int64_t rb = rbeg + (int64_t)blockIdx.x * XR;
+  if (id0 >= 0 && rb >= id0 && rb + XR <= id1 && rb - id0 >= j0 + PB) return;
+  const int nx = (int)max((int64_t)0, min((int64_t)XR, n_total - rb));
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  PT_DECL;
+  if (wave >= NW) {
+    // ------------------------------------------------------------ helpers: stage-in of blocks 1.., MFMA block updates
+    const int hid = tid - NTV, hw = wave - NW;
+    constexpr int CPT = ROWS * VPC / NTV;   // 16-byte vectors of one 16-column chunk per helper thread
+    vec_t cbuf[3][CPT];
+    auto chunk_load = [&](vec_t (&buf)[CPT], int c) {   // columns [16 c, 16 c + 16) of the rows from 16 c down
+#pragma unroll
+      for (int u = 0; u < CPT; ++u) {
+        const int idx = u * NTV + hid, r = idx / VPC, v = idx % VPC;
+        const int64_t grow = r < PB ? j0 + r : rb + (r - PB);
+        vec_t t;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) t[e] = T(0);
+        if (r >= c * CB && (r < PB || r - PB < nx)) t = *reinterpret_cast<const vec_t*>(&a[grow * lda + j0 + c * CB + v * VEC]);
+        buf[u] = t;
+      }
+    };
+    auto chunk_store = [&](const vec_t (&buf)[CPT], int c) {
+#pragma unroll
+      for (int u = 0; u < CPT; ++u) {
+        const int idx = u * NTV + hid, r = idx / VPC, v = idx % VPC;
+        if (r >= c * CB) *reinterpret_cast<vec_t*>(&S[r * LD + c * CB + v * VEC]) = buf[u];
+      }
+    };
+    const int fr = M::frag_row(lane), fk = M::frag_k(lane);
+    typename M::acc_t acc[TPW];
+    auto zero = [&](auto u0c) {
+      constexpr int U0 = decltype(u0c)::value;
+#pragma unroll
+      for (int u = U0; u < TPW; ++u)
+#pragma unroll
+        for (int i = 0; i < M::ACC; ++i) acc[u][i] = T(0);
+    };
+    auto accumulate = [&](auto u0c, int cn, int k0, int k1) {   // K columns [k0, k1) of the update of columns [cn, cn+16)
+      constexpr int U0 = decltype(u0c)::value;
+      if constexpr (U0 < TPW) {
+        const T* pb = &S[(cn + fr) * LD + fk];
+        const T* pa = &S[(hw * M::TM + fr) * LD + fk];
+        for (int kb = k0; kb < k1; kb += M::KSTEP) {
+          const typename M::vec_t bv = *reinterpret_cast<const typename M::vec_t*>(pb + kb);
+          typename M::vec_t av[TPW];
+#pragma unroll
+          for (int u = U0; u < TPW; ++u)
+            av[u] = *reinterpret_cast<const typename M::vec_t*>(pa + u * NW * M::TM * LD + kb);
+#pragma unroll
+          for (int i = 0; i < M::NK; ++i)
+#pragma unroll
+            for (int u = U0; u < TPW; ++u) M::mma1(acc[u], av[u][i], bv[i]);
+        }
+      }
+    };
+    auto finish = [&](auto u0c, int cb, int cn) {   // the block just finished, then C -= acc
+      constexpr int U0 = decltype(u0c)::value;
+      if constexpr (U0 < TPW) {
+        T cv[TPW][M::ACC];
+#pragma unroll
+        for (int u = U0; u < TPW; ++u) {
+          const int rt = (hw + u * NW) * M::TM;
+#pragma unroll
+          for (int i = 0; i < M::ACC; ++i) cv[u][i] = S[(rt + M::acc_row(lane, i)) * LD + cn + M::acc_col(lane)];
+        }
+        accumulate(u0c, cn, cb, cn);
+#pragma unroll
+        for (int u = U0; u < TPW; ++u) {
+          const int rt = (hw + u * NW) * M::TM;
+#pragma unroll
+          for (int i = 0; i < M::ACC; ++i) S[(rt + M::acc_row(lane, i)) * LD + cn + M::acc_col(lane)] = cv[u][i] - acc[u][i];
+        }
+      }
+    };
+    auto with_u0 = [&](int u0, auto&& f) {
+      switch (u0) {
+        case 0: f(std::integral_constant<int, 0>{}); break;
+        case 1: f(std::integral_constant<int, 1>{}); break;
+        case 2: f(std::integral_constant<int, 2>{}); break;
+        case 3: f(std::integral_constant<int, 3>{}); break;
+        default: break;
+      }
+    };
+    // block b: chunk b + 1 (loaded three blocks ago) goes to LDS, chunk b + 4 is requested into the same registers
+    auto hblock = [&](int b, auto slotc) {
+      constexpr int SLOT = decltype(slotc)::value;
+      const int cb = b * CB, cn = cb + CB;
+      const bool nb = b + 1 < NB;
+      const int first = cn / M::TM;                 // tiles above row cn are finished rows
+      const int u0 = first <= hw ? 0 : (first - hw + NW - 1) / NW;
+      if (nb) {
+        chunk_store(cbuf[SLOT], b + 1);
+        if (b + 4 < NB) chunk_load(cbuf[SLOT], b + 4);
+        with_u0(u0, [&](auto c) { zero(c); accumulate(c, cn, 0, cb); });
+        __syncthreads();                            // A: block b is solved in every row
+        with_u0(u0, [&](auto c) { finish(c, cb, cn); });
+        __syncthreads();                            // B: block b + 1 is up to date
+      }
+    };
+    chunk_load(cbuf[1], 1);
+    chunk_load(cbuf[2], 2);
+    chunk_load(cbuf[0], 3);
+    for (int b0 = 0; b0 < NB; b0 += 3) {
+      hblock(b0, std::integral_constant<int, 1>{});
+      if (b0 + 1 < NB) hblock(b0 + 1, std::integral_constant<int, 2>{});
+      if (b0 + 2 < NB) hblock(b0 + 2, std::integral_constant<int, 0>{});
+    }
+  } else {
+    // ------------------------------------------------------------ row threads: one leaf per 16-column block
+    const int row = tid, r16 = lane & 15;
+    const bool in_s = row < ROWS;
+    const bool has_g = in_s && (row < PB || row - PB < nx);
+    const int64_t grow = row < PB ? j0 + row : rb + (row - PB);
+    const int srow = in_s ? row : ROWS - 1;
+    T D[CB], V[CB];
+#pragma unroll
+    for (int q = 0; q < VPC; ++q) {   // block 0 straight from global memory
+      vec_t v;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) v[e] = T(0);
+      if (has_g) v = *reinterpret_cast<const vec_t*>(&a[grow * lda + j0 + q * VEC]);
+      const vec_t d = *reinterpret_cast<const vec_t*>(&a[(j0 + r16) * lda + j0 + q * VEC]);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        V[q * VEC + e] = v[e];
+        D[q * VEC + e] = -d[e];
+      }
+    }
+    T* const gdst = row < PB ? (blockIdx.x == 0 && ldiag_out ? ldiag_out + (int64_t)row * PB : nullptr)
+                             : (has_g ? a + grow * lda + j0 : nullptr);
+#pragma unroll 1
+    for (int b = 0; b < NB; ++b) {
+      const int cb = b * CB;
+      const bool live = 64 * (wave + 1) > cb;   // wave-uniform: some row of this wave is not finished yet
+      if (live) {
+        if (b > 0) {
+#pragma unroll
+          for (int q = 0; q < VPC; ++q) {
+            const vec_t v = *reinterpret_cast<const vec_t*>(&S[srow * LD + cb + q * VEC]);
+            const vec_t d = *reinterpret_cast<const vec_t*>(&S[(cb + r16) * LD + cb + q * VEC]);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+              V[q * VEC + e] = v[e];
+              D[q * VEC + e] = -d[e];
+            }
+          }
+        }
+        PT_MARK(0);
+        leaf::run(D, V);
+        PT_MARK(1);
+        if (in_s && row >= cb) {
+#pragma unroll
+          for (int q = 0; q < VPC; ++q) {
+            vec_t t;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) t[e] = V[q * VEC + e];
+            *reinterpret_cast<vec_t*>(&S[row * LD + cb + q * VEC]) = t;
+            if (gdst) *reinterpret_cast<vec_t*>(gdst + cb + q * VEC) = t;
+          }
+        }
+        PT_MARK(2);
+      }
+      if (b + 1 < NB) {
+        __syncthreads();   // A
+        PT_MARK(3);
+        __syncthreads();   // B
+        PT_MARK(4);
+      }
+    }
+#ifdef SMN_PANEL_TIMING
+    if (tid == NTV - 64 && j0 == 0 && blockIdx.x == 0)
+      printf("panelr wg0 last row wave (100 MHz ticks): load %lld  leaf %lld  store %lld  wait_A %lld  wait_B(tail) %lld\n",
+             pt_acc[0], pt_acc[1], pt_acc[2], pt_acc[3], pt_acc[4]);
+#endif
+  }
+  __syncthreads();
+  if (blockIdx.x == 0 && tid < 64) {
+    // logdet += 2 sum_j log L_jj; info = first pivot that is not a positive number (d <= 0 came out of the leaf as NaN)
+    const T d0 = S[tid * LD + tid], d1 = S[(tid + 64) * LD + tid + 64];
+    double lg = 2.0 * (log((double)d0) + log((double)d1));
+    int bad = !(d0 > T(0)) ? tid : (!(d1 > T(0)) ? tid + 64 : INT_MAX);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      lg += __shfl_xor(lg, o);
+      bad = min(bad, __shfl_xor(bad, o));
+    }
+    if (tid == 0) {
+      atomicAdd(logdet, lg);
+      if (bad != INT_MAX) atomicMin(info, (int)(j0 + bad + 1));
+    }
+  }
+}
+
 // Lower triangles of ALL factored diagonal blocks: side buffer -> matrix, once, after the last panel
 // (nothing inside the factorisation reads L_kk again; the LML / predictive heads never need it).
 template <typename T>
@@ -945,6 +1172,15 @@ int launch_panel_x(smn_ctx* ctx, hipStream_t st, T* a, int64_t lda, int64_t j0, 
   const int64_t rbeg = j0 + PB;
   const int64_t below = n_total - rbeg;
   const unsigned grid = below > 0 ? (unsigned)((below + XRV - 1) / XRV) : 1u;
+  if (ctx->panel_helpers >= 2 && !prefactored) {
+    ProfScope ps(ctx, PROF_PANEL, st);
+    T* ldiag = reinterpret_cast<T*>(ctx->ws[3]) + (j0 / PB) * (int64_t)(PB * PB);
+    auto kernr = panelr_kernel<T, XRV>;
+    hipLaunchKernelGGL(kernr, dim3(grid), dim3(2 * panel_threads(XRV)), panel_lds_bytes<T>(XRV), st, a, lda, j0, rbeg, n_total,
+                       ctx->d_scal, ctx->d_info, ldiag, ctx->chol_id0, ctx->chol_id1);
+    SMN_CHECK_LAUNCH(ctx);
+    return SMN_OK;
+  }
   if (ctx->panel_helpers && !prefactored) {
     ProfScope ps(ctx, PROF_PANEL, st);
     T* ldiag = reinterpret_cast<T*>(ctx->ws[3]) + (j0 / PB) * (int64_t)(PB * PB);
@@ -988,6 +1224,11 @@ int set_lds_attrs(smn_ctx* ctx) {
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)panel_lds_bytes<T>()));
   if constexpr (sizeof(T) == 4 && PanelCfg<T>::XR == 128)
     SMN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(panelh_kernel<T, 64>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)panel_lds_bytes<T>(64)));
+  SMN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(panelr_kernel<T>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)panel_lds_bytes<T>()));
+  if constexpr (sizeof(T) == 4 && PanelCfg<T>::XR == 128)
+    SMN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(panelr_kernel<T, 64>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)panel_lds_bytes<T>(64)));
   SMN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(update_kernel<T, 0>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -57,7 +57,7 @@ struct smn_ctx {
   bool chol_prepped = false;         // the caller has shifted the diagonal and reset logdet / info already (aug_prep)
   std::unordered_map<const void*, size_t> max_lds;   // largest dynamic-LDS size already allowed per kernel (smn_allow_lds)
   bool lds_attrs_done[2] = {false, false};   // hipFuncSetAttribute(MaxDynamicSharedMemorySize) issued for f32 / f64 kernels
-  bool panel_helpers = true;         // panelh_kernel: block updates on a second set of waves (env SMN_PANEL_HELPERS=0: panel_kernel)
+  int panel_helpers = 2;             // panel kernel of the factorisation: 2 panelr_kernel (register leaf), 1 panelh_kernel, 0 panel_kernel (env SMN_PANEL_HELPERS)
   int panel_small_rows = 4096;       // f32 panels with at most this many rows below use 64-row workgroups (env SMN_PANEL_SMALL)
   int quarter_tile_max = 256;        // update launches with at most this many 128x128 tiles use 64x64 tiles (env SMN_QUARTER_TILES)
   int half_tile_max = 384;           // ... and with at most this many, 64-row tiles (env SMN_HALF_TILES)

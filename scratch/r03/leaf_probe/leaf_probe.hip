@@ -1,0 +1,114 @@
+// r03 probe: a register-resident 16x16 Cholesky leaf with the TRSM of the lane's own row riding along.
+// Lane (r = lane & 15) holds a NEGATED copy of diagonal-tile row r in D[16]; its own row's 16 values in V[16].
+// Step k: rinv = rsq(d_kk) (DPP broadcast of lane k), scale column k, then for c > k:
+//   D_c += D_k * bcast_c(D_k)   V_c += V_k * bcast_c(D_k)     (row_newbcast:c reads lane c of the 16-lane row)
+// Variants: 1 = compiler (update_dpp + fmaf), 2 = inline asm v_fmac_f32_dpp.  HELP = a second wave per SIMD issuing MFMAs.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cmath>
+#include <vector>
+#include <utility>
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+template <int N> __device__ __forceinline__ float bc(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x150 + N, 0xf, 0xf, false));
+}
+__device__ __forceinline__ void leaf_compiler(float (&D)[16], float (&V)[16]) {
+  auto step = [&](auto kc) {
+    constexpr int K = decltype(kc)::value;
+    const float r = __builtin_amdgcn_rsqf(-bc<K>(D[K]));
+    D[K] *= r; V[K] *= r;
+    [&]<int... C>(std::integer_sequence<int, C...>) {
+      ((D[K + 1 + C] = fmaf(D[K], bc<K + 1 + C>(D[K]), D[K + 1 + C]), V[K + 1 + C] = fmaf(V[K], bc<K + 1 + C>(D[K]), V[K + 1 + C])), ...);
+    }(std::make_integer_sequence<int, 15 - K>{});
+  };
+  [&]<int... Ks>(std::integer_sequence<int, Ks...>) { (step(std::integral_constant<int, Ks>{}), ...); }(std::make_integer_sequence<int, 16>{});
+}
+__device__ __forceinline__ void leaf_asm(float (&D)[16], float (&V)[16]) {
+  float rinv;
+#include "leaf_asm.inc"
+}
+constexpr int LD = 20;
+template <int VAR, int HELP>
+__global__ void __launch_bounds__(512) probe(const float* __restrict__ dg, const float* __restrict__ bg, float* __restrict__ xg,
+                                             float* __restrict__ lg, long long* __restrict__ cyc, int iters) {
+  __shared__ __attribute__((aligned(16))) float Sd[16 * LD];
+  __shared__ __attribute__((aligned(16))) float Sv[256 * LD];
+  __shared__ char pad[100 * 1024];   // one workgroup per CU
+  const int tid = threadIdx.x;
+  if (tid == 0) pad[blockIdx.x & 1023] = 1;
+  if (tid < 256) {
+    for (int c = 0; c < 16; ++c) Sv[tid * LD + c] = bg[tid * 16 + c];
+    if (tid < 16) for (int c = 0; c < 16; ++c) Sd[tid * LD + c] = dg[tid * 16 + c];
+  }
+  __syncthreads();
+  if (tid >= 256) {
+    if (HELP) {   // second wave of every SIMD: dependent-free MFMA stream for the duration
+      f32x4 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+      float a = tid * 1e-3f, b = 1e-3f;
+      for (int it = 0; it < iters * HELP; ++it)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[u], 0, 0, 0);
+      if (acc[0][0] + acc[1][0] + acc[2][0] + acc[3][0] == 123.f) xg[0] = 1.f;
+    }
+    return;
+  }
+  float D[16], V[16];
+  const int r = tid & 15;
+  long long t0 = 0;
+  for (int it = 0; it <= iters; ++it) {
+    if (it == 1) t0 = __builtin_readcyclecounter();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 d = *reinterpret_cast<const f32x4*>(&Sd[r * LD + 4 * q]);
+      const f32x4 v = *reinterpret_cast<const f32x4*>(&Sv[tid * LD + 4 * q]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { D[4 * q + e] = -d[e]; V[4 * q + e] = v[e]; }
+    }
+    if (VAR == 1) leaf_compiler(D, V); else leaf_asm(D, V);
+    if (it == iters) break;
+    // keep the loop honest: results feed a dummy LDS write the next iteration does not read
+    *reinterpret_cast<f32x4*>(&Sv[tid * LD + 16]) = f32x4{V[0], V[5], D[10], V[15]};
+  }
+  const long long t1 = __builtin_readcyclecounter();
+  if ((tid & 63) == 0) cyc[blockIdx.x * 4 + (tid >> 6)] = t1 - t0;
+  for (int c = 0; c < 16; ++c) xg[tid * 16 + c] = V[c];
+  if (tid < 16) for (int c = 0; c < 16; ++c) lg[tid * 16 + c] = -D[c];
+}
+template <int VAR, int HELP>
+void run(const char* name, const float* d, const float* b, float* x, float* l, long long* cyc, const std::vector<double>& xr,
+         const std::vector<double>& lr) {
+  const int iters = 2000;
+  for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL((probe<VAR, HELP>), dim3(256), dim3(512), 0, 0, d, b, x, l, cyc, iters);
+  hipDeviceSynchronize();
+  std::vector<float> xh(256 * 16), lh(256);
+  std::vector<long long> ch(1024);
+  hipMemcpy(xh.data(), x, sizeof(float) * 4096, hipMemcpyDeviceToHost);
+  hipMemcpy(lh.data(), l, sizeof(float) * 256, hipMemcpyDeviceToHost);
+  hipMemcpy(ch.data(), cyc, sizeof(long long) * 1024, hipMemcpyDeviceToHost);
+  double ex = 0, el = 0, mx = 0;
+  for (int i = 0; i < 4096; ++i) { ex = fmax(ex, fabs(xh[i] - xr[i])); mx = fmax(mx, fabs(xr[i])); }
+  for (int i = 0; i < 16; ++i) for (int j = 0; j <= i; ++j) el = fmax(el, fabs(lh[i * 16 + j] - lr[i * 16 + j]));
+  double s = 0; for (auto c : ch) s += (double)c;
+  printf("%-28s cycles/leaf %.0f   max|X-Xref| %.2e (max|X| %.2f)  max|L-Lref| %.2e\n", name, s / 1024 / iters, ex, mx, el);
+}
+int main() {
+  std::vector<float> dh(256), bh(4096);
+  std::vector<double> a(256), lr(256, 0.0), xr(4096);
+  srand(1);
+  std::vector<double> g(16 * 24);
+  for (auto& v : g) v = rand() / (double)RAND_MAX - 0.5;
+  for (int i = 0; i < 16; ++i) for (int j = 0; j < 16; ++j) { double s = i == j ? 0.5 : 0; for (int k = 0; k < 24; ++k) s += g[i * 24 + k] * g[j * 24 + k]; a[i * 16 + j] = s; dh[i * 16 + j] = (float)s; }
+  for (auto& v : bh) v = (float)(rand() / (double)RAND_MAX - 0.5);
+  for (int j = 0; j < 16; ++j) { double d = dh[j * 16 + j]; for (int k = 0; k < j; ++k) d -= lr[j * 16 + k] * lr[j * 16 + k]; lr[j * 16 + j] = sqrt(d);
+    for (int i = j + 1; i < 16; ++i) { double s = dh[i * 16 + j]; for (int k = 0; k < j; ++k) s -= lr[i * 16 + k] * lr[j * 16 + k]; lr[i * 16 + j] = s / lr[j * 16 + j]; } }
+  for (int r = 0; r < 256; ++r) for (int c = 0; c < 16; ++c) { double s = bh[r * 16 + c]; for (int k = 0; k < c; ++k) s -= xr[r * 16 + k] * lr[c * 16 + k]; xr[r * 16 + c] = s / lr[c * 16 + c]; }
+  float *d, *b, *x, *l; long long* cyc;
+  hipMalloc(&d, 1024); hipMalloc(&b, 16384); hipMalloc(&x, 16384); hipMalloc(&l, 1024); hipMalloc(&cyc, 8192);
+  hipMemcpy(d, dh.data(), 1024, hipMemcpyHostToDevice); hipMemcpy(b, bh.data(), 16384, hipMemcpyHostToDevice);
+  run<1, 0>("compiler dpp, alone", d, b, x, l, cyc, xr, lr);
+  run<2, 0>("asm fmac_dpp, alone", d, b, x, l, cyc, xr, lr);
+  run<1, 12>("compiler dpp, + MFMA wave", d, b, x, l, cyc, xr, lr);
+  run<2, 9>("asm fmac_dpp, + MFMA wave", d, b, x, l, cyc, xr, lr);
+  return 0;
+}
