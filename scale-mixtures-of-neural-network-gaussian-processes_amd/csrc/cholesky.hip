@@ -98,9 +98,23 @@ struct PanelMma<double> {  // v_mfma_f64_16x16x4_f64
 
 template <typename T>
 constexpr size_t panel_lds_bytes(int xr = PanelCfg<T>::XR) {
+#ifdef SMN_PANEL_TIMING
+  return sizeof(T) * ((size_t)(PB + xr) * PanelCfg<T>::LD + MP * MP + PB) + 2048;   // room for panelr_kernel's timeline
+#else
   return sizeof(T) * ((size_t)(PB + xr) * PanelCfg<T>::LD + MP * MP + PB);
+#endif
 }
 constexpr int panel_threads(int xr) { return (PB + xr + 63) / 64 * 64; }   // one thread per LDS row, whole waves
+// panelr_kernel: the image + one private copy of the first diagonal tile per row wave (+ the timeline of the timing build)
+constexpr int kLeafTileLd(size_t elem) { return 16 + 16 / (int)elem; }
+template <typename T>
+constexpr size_t panelr_lds_bytes(int xr = PanelCfg<T>::XR) {
+  return sizeof(T) * ((size_t)(PB + xr) * PanelCfg<T>::LD + (size_t)(panel_threads(xr) / 64) * 16 * kLeafTileLd(sizeof(T)))
+#ifdef SMN_PANEL_TIMING
+         + 4096
+#endif
+      ;
+}
 
 #ifdef SMN_PANEL_TIMING   // debug build only: phase times of workgroup 0 of the first panel, printed by the kernel
 #define PT_DECL long long pt_t = wall_clock64(), pt_acc[6] = {0, 0, 0, 0, 0, 0}; (void)pt_acc
@@ -594,18 +608,18 @@ __global__ void __launch_bounds__(2 * panel_threads(XRV)) panelh_kernel(T* __res
 }
 
 // panelr_kernel — the form the factorisation launches from round 3 on: the 8-column in-LDS micro-panels are replaced by
-// a register-resident 16x16 leaf (panel_leaf.hpp).
-//   Row threads (waves [0, NW), one LDS row each): per 16-column block, load the lane's own 16 entries and a copy of
-//   diagonal-tile row (lane & 15), run the leaf (factor + TRSM of the own row through DPP row_newbcast: no LDS traffic,
-//   no barrier inside the block), write the solved entries back to the LDS image AND straight to global memory (the
-//   appended rows' columns of this block are final: nothing is left to store when the last block is done).
-//   Helper waves ([NW, 2 NW)): stream the raw columns of the blocks to come from global memory into LDS three blocks
-//   ahead of their use (the row threads take block 0 straight into registers, so the first leaf starts after ONE
-//   global round trip instead of after the whole 128 KB image has landed), and bring the next block's columns up to
-//   date with MFMAs exactly as in panelh_kernel: K = [0, cb) beside the leaf, the block just finished behind it.
-// Two workgroup barriers per block (leaf done / next block up to date) instead of panelh_kernel's five.
-// Cost (profiles/r03_*): one wave issues a vector instruction every ~6.5 cycles, so the leaf's 288 are ~0.85 us of the
-// ~1.2 us a block takes; the sub-panel is ~11 us against 27.
+// a register-resident 16x16 leaf (panel_leaf.hpp).  Per 16-column block b (columns cb .. cb+15, cn = cb + 16):
+//   Row threads (waves [0, NW), one LDS row each) load the lane's own 16 entries and a copy of diagonal-tile row
+//   (lane & 15), run the leaf (factor + TRSM of the own row through DPP row_newbcast: no LDS traffic, no barrier inside
+//   the block) and write the solved entries back to the LDS image.                                     -- barrier A --
+//   They then send the same registers straight to global memory (the appended rows' columns of this block are final:
+//   nothing is left to store when the last block is done) while ALL waves bring block b+1's columns up to date with
+//   every finished column (at most two 16x16 tiles per wave, K = cn).                                  -- barrier B --
+//   Helper waves ([NW, 2 NW)) stream the raw columns of the blocks to come from global memory into LDS beside the leaf
+//   (three chunks in flight; the row threads take block 0 straight into registers, so the first leaf starts after ONE
+//   global round trip instead of after the whole 128 KB image) and are the other half of the MFMA phase.
+// Two workgroup barriers per block instead of panelh_kernel's five.  One wave issues a vector instruction every ~6.5
+// cycles (profiles/r03_valu_issue_rate.txt), so the leaf's 288 are ~0.85 us per block and half of the sub-panel.
 template <typename T, int XRV = PanelCfg<T>::XR>
 __global__ void __launch_bounds__(2 * panel_threads(XRV)) panelr_kernel(T* __restrict__ a, int64_t lda, int64_t j0,
                                                                           int64_t rbeg, int64_t n_total,
@@ -620,19 +634,111 @@ __global__ void __launch_bounds__(2 * panel_threads(XRV)) panelr_kernel(T* __res
   using M = PanelMma<T>;
   constexpr int NW = NTV / 64;
   constexpr int RT = ROWS / M::TM;
-  constexpr int TPW = (RT + NW - 1) / NW;
-  static_assert(RT % NW == 0 && TPW <= 4, "tile split over the helper waves");
   static_assert((ROWS * VPC) % NTV == 0, "chunk vectors split evenly over the helper threads");
+  static_assert(RT - 1 <= 2 * 2 * NW, "update() gives every wave at most two tiles");
   T* S = reinterpret_cast<T*>(smem);        // [PB + XR][LD]
   const int tid = threadIdx.x;
   const int64_t rb = rbeg + (int64_t)blockIdx.x * XR;
   if (id0 >= 0 && rb >= id0 && rb + XR <= id1 && rb - id0 >= j0 + PB) return;
   const int nx = (int)max((int64_t)0, min((int64_t)XR, n_total - rb));
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  PT_DECL;
+  const int fr = M::frag_row(lane), fk = M::frag_k(lane);
+  // Block b+1's columns brought up to date with every finished column: S[t, cn:cn+16] -= S[t, 0:cn] S[cn:cn+16, 0:cn]^T
+  // for the tiles t from `first` down, dealt round-robin to all 2 NW waves (at most two per wave: two independent
+  // accumulators, one B fragment).  It runs BEHIND the leaf, not beside it: f32 MFMAs and vector instructions of two
+  // waves on one SIMD do not overlap (each MFMA of a partner wave costs the leaf its full 32 cycles,
+  // profiles/r03_leaf_probe.txt), so a helper pass beside the leaf only stretches the critical path.
+  auto update = [&](int cn, int first) {
+    int rt[2];
+    bool on[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int t = first + wave + j * 2 * NW;
+      on[j] = t < RT;
+      rt[j] = (on[j] ? t : first + wave) * M::TM;
+    }
+    if (!on[0]) return;   // wave-uniform: nothing for this wave (on[1] implies on[0])
+    T cv[2][M::ACC];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int i = 0; i < M::ACC; ++i) cv[j][i] = S[(rt[j] + M::acc_row(lane, i)) * LD + cn + M::acc_col(lane)];
+    typename M::acc_t acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int i = 0; i < M::ACC; ++i) acc[j][i] = T(0);
+    const T* pb = &S[(cn + fr) * LD + fk];
+    const T* pa0 = &S[(rt[0] + fr) * LD + fk];
+    const T* pa1 = &S[(rt[1] + fr) * LD + fk];
+    // Two fragment sets, ping-pong: the reads of K-step s+1 are issued, THEN the MFMAs of step s (sched_barrier keeps the
+    // order; written as a plain prefetch loop hipcc folds it back into read -> wait -> MFMA, 420 cycles per step for 256 of
+    // MFMAs).  Reads past the end are clamped to the last step, so no branch sits between the reads and the MFMAs.
+    using cvp = const typename M::vec_t*;
+    const int klast = cn - M::KSTEP;
+    auto kloop = [&](auto twoc) {
+      constexpr bool TWO = decltype(twoc)::value;
+      typename M::vec_t b0, x0, y0, b1, x1, y1;
+      auto rd = [&](typename M::vec_t& bq, typename M::vec_t& xq, typename M::vec_t& yq, int kb) {
+        bq = *reinterpret_cast<cvp>(pb + kb);
+        xq = *reinterpret_cast<cvp>(pa0 + kb);
+        if (TWO) yq = *reinterpret_cast<cvp>(pa1 + kb);
+      };
+      auto mm = [&](const typename M::vec_t& bq, const typename M::vec_t& xq, const typename M::vec_t& yq) {
+#pragma unroll
+        for (int i = 0; i < M::NK; ++i) {
+          M::mma1(acc[0], xq[i], bq[i]);
+          if (TWO) M::mma1(acc[1], yq[i], bq[i]);
+        }
+      };
+      rd(b0, x0, y0, 0);
+      for (int kb = 0;;) {
+        rd(b1, x1, y1, min(kb + M::KSTEP, klast));
+        __builtin_amdgcn_sched_barrier(0);
+        mm(b0, x0, y0);
+        kb += M::KSTEP;
+        if (kb >= cn) break;
+        rd(b0, x0, y0, min(kb + M::KSTEP, klast));
+        __builtin_amdgcn_sched_barrier(0);
+        mm(b1, x1, y1);
+        kb += M::KSTEP;
+        if (kb >= cn) break;
+      }
+    };
+    if (on[1]) kloop(std::true_type{}); else kloop(std::false_type{});
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      if (on[j]) {
+#pragma unroll
+        for (int i = 0; i < M::ACC; ++i) S[(rt[j] + M::acc_row(lane, i)) * LD + cn + M::acc_col(lane)] = cv[j][i] - acc[j][i];
+      }
+  };
+  // Block c's columns are final once its leaf is done: they leave for global memory (the appended rows' entries of L^-T
+  // products in place, the factored diagonal block to the side buffer) in the chunk layout -- VPC lanes per row -- by
+  // `nthr` threads that have nothing else to do (the helper waves beside the next leaf; everybody after the last one).
+  auto store_out = [&](int c, int t0, int nthr) {
+    for (int idx = t0; idx < ROWS * VPC; idx += nthr) {
+      const int r = idx / VPC, v = idx % VPC;
+      if (r < c * CB) continue;
+      T* dst = nullptr;
+      if (r < PB) {
+        if (blockIdx.x == 0 && ldiag_out) dst = ldiag_out + (int64_t)r * PB;
+      } else if (r - PB < nx) {
+        dst = a + (rb + (r - PB)) * lda + j0;
+      }
+      if (dst) *reinterpret_cast<vec_t*>(dst + c * CB + v * VEC) = *reinterpret_cast<const vec_t*>(&S[r * LD + c * CB + v * VEC]);
+    }
+  };
+#ifdef SMN_PANEL_TIMING   // timeline of wg 0 of the first panel: ticks (100 MHz) since kernel start, per block, per wave, 6 marks
+  int* const tlog = reinterpret_cast<int*>(S + ROWS * LD + NW * CB * kLeafTileLd(sizeof(T)));
+  const long long tl0 = wall_clock64();
+#define TL(b, i) do { if (lane == 0 && blockIdx.x == 0 && j0 == 0) tlog[(wave * NB + (b)) * 6 + (i)] = (int)(wall_clock64() - tl0); } while (0)
+#else
+#define TL(b, i)
+#endif
   if (wave >= NW) {
-    // ------------------------------------------------------------ helpers: stage-in of blocks 1.., MFMA block updates
-    const int hid = tid - NTV, hw = wave - NW;
+    // ------------------------------------------------------------ helpers: stage-in of blocks 1..
+    const int hid = tid - NTV;
     constexpr int CPT = ROWS * VPC / NTV;   // 16-byte vectors of one 16-column chunk per helper thread
     vec_t cbuf[3][CPT];
     auto chunk_load = [&](vec_t (&buf)[CPT], int c) {   // columns [16 c, 16 c + 16) of the rows from 16 c down
@@ -654,128 +760,94 @@ __global__ void __launch_bounds__(2 * panel_threads(XRV)) panelr_kernel(T* __res
         if (r >= c * CB) *reinterpret_cast<vec_t*>(&S[r * LD + c * CB + v * VEC]) = buf[u];
       }
     };
-    const int fr = M::frag_row(lane), fk = M::frag_k(lane);
-    typename M::acc_t acc[TPW];
-    auto zero = [&](auto u0c) {
-      constexpr int U0 = decltype(u0c)::value;
-#pragma unroll
-      for (int u = U0; u < TPW; ++u)
-#pragma unroll
-        for (int i = 0; i < M::ACC; ++i) acc[u][i] = T(0);
-    };
-    auto accumulate = [&](auto u0c, int cn, int k0, int k1) {   // K columns [k0, k1) of the update of columns [cn, cn+16)
-      constexpr int U0 = decltype(u0c)::value;
-      if constexpr (U0 < TPW) {
-        const T* pb = &S[(cn + fr) * LD + fk];
-        const T* pa = &S[(hw * M::TM + fr) * LD + fk];
-        for (int kb = k0; kb < k1; kb += M::KSTEP) {
-          const typename M::vec_t bv = *reinterpret_cast<const typename M::vec_t*>(pb + kb);
-          typename M::vec_t av[TPW];
-#pragma unroll
-          for (int u = U0; u < TPW; ++u)
-            av[u] = *reinterpret_cast<const typename M::vec_t*>(pa + u * NW * M::TM * LD + kb);
-#pragma unroll
-          for (int i = 0; i < M::NK; ++i)
-#pragma unroll
-            for (int u = U0; u < TPW; ++u) M::mma1(acc[u], av[u][i], bv[i]);
-        }
-      }
-    };
-    auto finish = [&](auto u0c, int cb, int cn) {   // the block just finished, then C -= acc
-      constexpr int U0 = decltype(u0c)::value;
-      if constexpr (U0 < TPW) {
-        T cv[TPW][M::ACC];
-#pragma unroll
-        for (int u = U0; u < TPW; ++u) {
-          const int rt = (hw + u * NW) * M::TM;
-#pragma unroll
-          for (int i = 0; i < M::ACC; ++i) cv[u][i] = S[(rt + M::acc_row(lane, i)) * LD + cn + M::acc_col(lane)];
-        }
-        accumulate(u0c, cn, cb, cn);
-#pragma unroll
-        for (int u = U0; u < TPW; ++u) {
-          const int rt = (hw + u * NW) * M::TM;
-#pragma unroll
-          for (int i = 0; i < M::ACC; ++i) S[(rt + M::acc_row(lane, i)) * LD + cn + M::acc_col(lane)] = cv[u][i] - acc[u][i];
-        }
-      }
-    };
-    auto with_u0 = [&](int u0, auto&& f) {
-      switch (u0) {
-        case 0: f(std::integral_constant<int, 0>{}); break;
-        case 1: f(std::integral_constant<int, 1>{}); break;
-        case 2: f(std::integral_constant<int, 2>{}); break;
-        case 3: f(std::integral_constant<int, 3>{}); break;
-        default: break;
-      }
-    };
-    // block b: chunk b + 1 (loaded three blocks ago) goes to LDS, chunk b + 4 is requested into the same registers
+    // Block b: chunk b+1 (requested three chunks ago) goes to LDS -- its first reader is update() behind barrier A --
+    // and chunk b+4 is requested into the same registers.
     auto hblock = [&](int b, auto slotc) {
       constexpr int SLOT = decltype(slotc)::value;
-      const int cb = b * CB, cn = cb + CB;
-      const bool nb = b + 1 < NB;
-      const int first = cn / M::TM;                 // tiles above row cn are finished rows
-      const int u0 = first <= hw ? 0 : (first - hw + NW - 1) / NW;
-      if (nb) {
+      if (b >= NB) return;
+      TL(b, 0);
+      if (b + 1 < NB) {
         chunk_store(cbuf[SLOT], b + 1);
         if (b + 4 < NB) chunk_load(cbuf[SLOT], b + 4);
-        with_u0(u0, [&](auto c) { zero(c); accumulate(c, cn, 0, cb); });
-        __syncthreads();                            // A: block b is solved in every row
-        with_u0(u0, [&](auto c) { finish(c, cb, cn); });
-        __syncthreads();                            // B: block b + 1 is up to date
       }
+      if (b > 0) store_out(b - 1, hid, NTV);        // beside leaf b
+      TL(b, 2);
+      if (b + 1 >= NB) return;
+      __syncthreads();                              // A: block b is solved in every row
+      TL(b, 3);
+      update((b + 1) * CB, b + 1);
+      TL(b, 4);
+      __syncthreads();                              // B: block b + 1 is up to date
+      TL(b, 5);
     };
     chunk_load(cbuf[1], 1);
     chunk_load(cbuf[2], 2);
     chunk_load(cbuf[0], 3);
-    for (int b0 = 0; b0 < NB; b0 += 3) {
+    for (int b0 = 0; b0 < NB; b0 += 3) {   // chunk b + 1 lives in slot (b + 1) % 3
       hblock(b0, std::integral_constant<int, 1>{});
-      if (b0 + 1 < NB) hblock(b0 + 1, std::integral_constant<int, 2>{});
-      if (b0 + 2 < NB) hblock(b0 + 2, std::integral_constant<int, 0>{});
+      hblock(b0 + 1, std::integral_constant<int, 2>{});
+      hblock(b0 + 2, std::integral_constant<int, 0>{});
     }
   } else {
     // ------------------------------------------------------------ row threads: one leaf per 16-column block
     const int row = tid, r16 = lane & 15;
     const bool in_s = row < ROWS;
-    const bool has_g = in_s && (row < PB || row - PB < nx);
-    const int64_t grow = row < PB ? j0 + row : rb + (row - PB);
     const int srow = in_s ? row : ROWS - 1;
     T D[CB], V[CB];
+    constexpr int TLD = kLeafTileLd(sizeof(T));
+    T* const tile0 = S + ROWS * LD + wave * CB * TLD;
+    {
+      // Block 0 of this wave's own 64 rows and of the diagonal tile: VPC lanes per row (whole 64-byte row pieces per
+      // request instead of one 16-byte piece per row and lane: a quarter of the cache-line look-ups, and the tile is
+      // fetched once per wave, not once per 16 lanes), through LDS: the rows into the image, the tile into a private
+      // copy per wave (another wave may already have written its solved rows over the image's tile).  LDS operations of
+      // one wave execute in order, so the wave reads back what it wrote: no barrier.
+      vec_t own[VPC], dg[(CB * VPC + 63) / 64];
 #pragma unroll
-    for (int q = 0; q < VPC; ++q) {   // block 0 straight from global memory
-      vec_t v;
+      for (int u = 0; u < VPC; ++u) {
+        const int idx = u * 64 + lane, r = wave * 64 + idx / VPC, v = idx % VPC;
+        const int64_t gr = r < PB ? j0 + r : rb + (r - PB);
+        vec_t t;
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) v[e] = T(0);
-      if (has_g) v = *reinterpret_cast<const vec_t*>(&a[grow * lda + j0 + q * VEC]);
-      const vec_t d = *reinterpret_cast<const vec_t*>(&a[(j0 + r16) * lda + j0 + q * VEC]);
+        for (int e = 0; e < VEC; ++e) t[e] = T(0);
+        if (r < ROWS && (r < PB || r - PB < nx)) t = *reinterpret_cast<const vec_t*>(&a[gr * lda + j0 + v * VEC]);
+        own[u] = t;
+      }
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) {
-        V[q * VEC + e] = v[e];
-        D[q * VEC + e] = -d[e];
+      for (int u = 0; u < (CB * VPC + 63) / 64; ++u) {
+        const int idx = u * 64 + lane, r = idx / VPC, v = idx % VPC;
+        if (idx < CB * VPC) dg[u] = *reinterpret_cast<const vec_t*>(&a[(j0 + r) * lda + j0 + v * VEC]);
+      }
+#pragma unroll
+      for (int u = 0; u < VPC; ++u) {
+        const int idx = u * 64 + lane, r = wave * 64 + idx / VPC, v = idx % VPC;
+        if (r < ROWS) *reinterpret_cast<vec_t*>(&S[r * LD + v * VEC]) = own[u];
+      }
+#pragma unroll
+      for (int u = 0; u < (CB * VPC + 63) / 64; ++u) {
+        const int idx = u * 64 + lane, r = idx / VPC, v = idx % VPC;
+        if (idx < CB * VPC) *reinterpret_cast<vec_t*>(&tile0[r * TLD + v * VEC]) = dg[u];
       }
     }
-    T* const gdst = row < PB ? (blockIdx.x == 0 && ldiag_out ? ldiag_out + (int64_t)row * PB : nullptr)
-                             : (has_g ? a + grow * lda + j0 : nullptr);
 #pragma unroll 1
     for (int b = 0; b < NB; ++b) {
       const int cb = b * CB;
       const bool live = 64 * (wave + 1) > cb;   // wave-uniform: some row of this wave is not finished yet
       if (live) {
-        if (b > 0) {
 #pragma unroll
-          for (int q = 0; q < VPC; ++q) {
-            const vec_t v = *reinterpret_cast<const vec_t*>(&S[srow * LD + cb + q * VEC]);
-            const vec_t d = *reinterpret_cast<const vec_t*>(&S[(cb + r16) * LD + cb + q * VEC]);
+        for (int q = 0; q < VPC; ++q) {
+          const vec_t v = *reinterpret_cast<const vec_t*>(&S[srow * LD + cb + q * VEC]);
+          const vec_t d = b == 0 ? *reinterpret_cast<const vec_t*>(&tile0[r16 * TLD + q * VEC])
+                                 : *reinterpret_cast<const vec_t*>(&S[(cb + r16) * LD + cb + q * VEC]);
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-              V[q * VEC + e] = v[e];
-              D[q * VEC + e] = -d[e];
-            }
+          for (int e = 0; e < VEC; ++e) {
+            V[q * VEC + e] = v[e];
+            D[q * VEC + e] = d[e];
           }
         }
-        PT_MARK(0);
+        TL(b, 0);
         leaf::run(D, V);
-        PT_MARK(1);
+        TL(b, 1);
         if (in_s && row >= cb) {
 #pragma unroll
           for (int q = 0; q < VPC; ++q) {
@@ -783,25 +855,31 @@ __global__ void __launch_bounds__(2 * panel_threads(XRV)) panelr_kernel(T* __res
 #pragma unroll
             for (int e = 0; e < VEC; ++e) t[e] = V[q * VEC + e];
             *reinterpret_cast<vec_t*>(&S[row * LD + cb + q * VEC]) = t;
-            if (gdst) *reinterpret_cast<vec_t*>(gdst + cb + q * VEC) = t;
           }
         }
-        PT_MARK(2);
+        TL(b, 2);
       }
+      if (b + 1 < NB) __syncthreads();   // A
+      TL(b, 3);
       if (b + 1 < NB) {
-        __syncthreads();   // A
-        PT_MARK(3);
+        update(cb + CB, b + 1);
+        TL(b, 4);
         __syncthreads();   // B
-        PT_MARK(4);
+        TL(b, 5);
       }
     }
-#ifdef SMN_PANEL_TIMING
-    if (tid == NTV - 64 && j0 == 0 && blockIdx.x == 0)
-      printf("panelr wg0 last row wave (100 MHz ticks): load %lld  leaf %lld  store %lld  wait_A %lld  wait_B(tail) %lld\n",
-             pt_acc[0], pt_acc[1], pt_acc[2], pt_acc[3], pt_acc[4]);
-#endif
   }
   __syncthreads();
+#ifdef SMN_PANEL_TIMING
+  if (tid == 0 && blockIdx.x == 0 && j0 == 0)
+    for (int w = 0; w < 2 * NW; ++w)
+      for (int b = 0; b < NB; ++b)
+        printf("panelr wave %d block %d: %s %5d  %s %5d  %s %5d  A %5d  upd %5d  B %5d\n", w, b, w < NW ? "leaf0" : "chnk0", tlog[(w * NB + b) * 6 + 0],
+               w < NW ? "leaf1" : "  -  ", tlog[(w * NB + b) * 6 + 1], w < NW ? "stor" : "chnk", tlog[(w * NB + b) * 6 + 2], tlog[(w * NB + b) * 6 + 3],
+               tlog[(w * NB + b) * 6 + 4], tlog[(w * NB + b) * 6 + 5]);
+#endif
+#undef TL
+  store_out(NB - 1, tid, 2 * NTV);
   if (blockIdx.x == 0 && tid < 64) {
     // logdet += 2 sum_j log L_jj; info = first pivot that is not a positive number (d <= 0 came out of the leaf as NaN)
     const T d0 = S[tid * LD + tid], d1 = S[(tid + 64) * LD + tid + 64];
@@ -1176,7 +1254,7 @@ int launch_panel_x(smn_ctx* ctx, hipStream_t st, T* a, int64_t lda, int64_t j0, 
     ProfScope ps(ctx, PROF_PANEL, st);
     T* ldiag = reinterpret_cast<T*>(ctx->ws[3]) + (j0 / PB) * (int64_t)(PB * PB);
     auto kernr = panelr_kernel<T, XRV>;
-    hipLaunchKernelGGL(kernr, dim3(grid), dim3(2 * panel_threads(XRV)), panel_lds_bytes<T>(XRV), st, a, lda, j0, rbeg, n_total,
+    hipLaunchKernelGGL(kernr, dim3(grid), dim3(2 * panel_threads(XRV)), panelr_lds_bytes<T>(XRV), st, a, lda, j0, rbeg, n_total,
                        ctx->d_scal, ctx->d_info, ldiag, ctx->chol_id0, ctx->chol_id1);
     SMN_CHECK_LAUNCH(ctx);
     return SMN_OK;
@@ -1226,10 +1304,10 @@ int set_lds_attrs(smn_ctx* ctx) {
     SMN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(panelh_kernel<T, 64>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)panel_lds_bytes<T>(64)));
   SMN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(panelr_kernel<T>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)panel_lds_bytes<T>()));
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)panelr_lds_bytes<T>()));
   if constexpr (sizeof(T) == 4 && PanelCfg<T>::XR == 128)
     SMN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(panelr_kernel<T, 64>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)panel_lds_bytes<T>(64)));
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)panelr_lds_bytes<T>(64)));
   SMN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(update_kernel<T, 0>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)MainTile<T>::LDS_BYTES));

@@ -1,13 +1,13 @@
 // panel_leaf.hpp — the register-resident 16x16 leaf of the Cholesky panel (panelr_kernel, cholesky.hip).
 //
-// Every 16-lane row of a wave holds a copy of the 16x16 diagonal tile, one tile row per lane (lane & 15), NEGATED, in
+// Every 16-lane row of a wave holds a copy of the 16x16 diagonal tile, one tile row per lane (lane & 15), in
 // D[16]; every lane also holds 16 entries of ITS OWN matrix row (the tile's columns) in V[16].  Sixteen elimination
 // steps factor the tile (redundantly in every 16-lane row) and carry the lane's own row through the same column
 // operations -- x L^T = b, a true TRSM without an inverse -- with the multipliers L_ck read from lane c of the
 // 16-lane row by DPP row_newbcast inside the fused multiply-add itself: no LDS, no barrier, no cross-wave traffic.
-//   step k:  rinv = rsqrt(d_kk);  D_k *= rinv;  V_k *= rinv;  for c > k:  D_c += bcast_c(D_k) D_k,  V_c += bcast_c(D_k) V_k
+//   step k:  rinv = rsqrt(d_kk);  D_k *= rinv;  V_k *= rinv;  for c > k:  D_c -= bcast_c(D_k) D_k,  V_c -= bcast_c(D_k) V_k
 // On exit V = b L^-T (for a lane whose own row IS tile row r: row r of L, with garbage right of the diagonal that
-// nothing reads), D = -L rows (unused).  288 vector instructions per 16 columns (f32); a non-positive pivot turns
+// nothing reads), D = L rows (unused).  288 vector instructions per 16 columns (f32); a non-positive pivot turns
 // into NaN (rsqrt of a negative number, 0 * inf) and propagates, which is how the caller detects it.
 // Replaces the in-LDS micro-panels of panel_kernel on the path of lax.linalg.cholesky (spax/utils.py:179).
 #pragma once
@@ -36,7 +36,7 @@ __device__ __forceinline__ double rsqrt_pivot(double d) {
   return __builtin_fma(y * e, __builtin_fma(0.375, e, 0.5), y);
 }
 
-#define LEAF_RINV(K) rinv = rsqrt_pivot(-bcast<K>(D[K]));
+#define LEAF_RINV(K) rinv = rsqrt_pivot(bcast<K>(D[K]));
 
 __device__ __forceinline__ void run(float (&D)[16], float (&V)[16]) {
   float rinv;

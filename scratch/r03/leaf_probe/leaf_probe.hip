@@ -24,12 +24,14 @@ __device__ __forceinline__ void leaf_compiler(float (&D)[16], float (&V)[16]) {
   };
   [&]<int... Ks>(std::integer_sequence<int, Ks...>) { (step(std::integral_constant<int, Ks>{}), ...); }(std::make_integer_sequence<int, 16>{});
 }
-__device__ __forceinline__ void leaf_asm(float (&D)[16], float (&V)[16]) {
-  float rinv;
-#include "leaf_asm.inc"
+#include "../../../scale-mixtures-of-neural-network-gaussian-processes_amd/csrc/panel_leaf.hpp"
+__device__ __forceinline__ void leaf_asm(float (&D)[16], float (&V)[16]) {   // product leaf wants +D
+  for (int i = 0; i < 16; ++i) D[i] = -D[i];
+  leaf::run(D, V);
+  for (int i = 0; i < 16; ++i) D[i] = -D[i];
 }
 constexpr int LD = 20;
-template <int VAR, int HELP>
+template <int VAR, int HELP, int PM = 0>
 __global__ void __launch_bounds__(512) probe(const float* __restrict__ dg, const float* __restrict__ bg, float* __restrict__ xg,
                                              float* __restrict__ lg, long long* __restrict__ cyc, int iters) {
   __shared__ __attribute__((aligned(16))) float Sd[16 * LD];
@@ -43,12 +45,44 @@ __global__ void __launch_bounds__(512) probe(const float* __restrict__ dg, const
   }
   __syncthreads();
   if (tid >= 256) {
-    if (HELP) {   // second wave of every SIMD: dependent-free MFMA stream for the duration
+    if (HELP) {   // second wave of every SIMD for the duration: PM 0 MFMAs only, 1 LDS reads only, 2 the panel's mix (5 reads per 16 MFMAs)
       f32x4 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
       float a = tid * 1e-3f, b = 1e-3f;
-      for (int it = 0; it < iters * HELP; ++it)
+      const float* base = &Sv[((tid & 15) * LD) + (tid >> 4 & 3) * 4];
+      for (int it = 0; it < iters * HELP; ++it) {
+        if (PM == 0) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[u], 0, 0, 0);
+          for (int u = 0; u < 4; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[u], 0, 0, 0);
+        } else if (PM == 1) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) { const f32x4 v = *reinterpret_cast<const volatile f32x4*>(base + u * 16 * LD); acc[u] += v; }
+        } else if (PM == 3) {   // MFMAs over 20 different register operands, no LDS
+          f32x4 v[5];
+#pragma unroll
+          for (int u = 0; u < 5; ++u) { v[u] = f32x4{a + u, b + u, a - u, b - u}; asm volatile("" : "+v"(v[u])); }
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[u][i], v[4][i], acc[u], 0, 0, 0);
+        } else if (PM == 4) {   // the reads and the MFMAs of the mix, but the MFMAs do not wait for the reads
+          f32x4 v[5];
+#pragma unroll
+          for (int u = 0; u < 5; ++u) v[u] = *reinterpret_cast<const volatile f32x4*>(base + u * 16 * LD);
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[u], 0, 0, 0);
+          if (v[0][0] + v[1][1] + v[2][2] + v[3][3] + v[4][0] == 77.f) a += 1.f;
+        } else {
+          f32x4 v[5];
+#pragma unroll
+          for (int u = 0; u < 5; ++u) v[u] = *reinterpret_cast<const volatile f32x4*>(base + u * 16 * LD);
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[u][i], v[4][i], acc[u], 0, 0, 0);
+        }
+      }
       if (acc[0][0] + acc[1][0] + acc[2][0] + acc[3][0] == 123.f) xg[0] = 1.f;
     }
     return;
@@ -75,11 +109,11 @@ __global__ void __launch_bounds__(512) probe(const float* __restrict__ dg, const
   for (int c = 0; c < 16; ++c) xg[tid * 16 + c] = V[c];
   if (tid < 16) for (int c = 0; c < 16; ++c) lg[tid * 16 + c] = -D[c];
 }
-template <int VAR, int HELP>
+template <int VAR, int HELP, int PM = 0>
 void run(const char* name, const float* d, const float* b, float* x, float* l, long long* cyc, const std::vector<double>& xr,
          const std::vector<double>& lr) {
   const int iters = 2000;
-  for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL((probe<VAR, HELP>), dim3(256), dim3(512), 0, 0, d, b, x, l, cyc, iters);
+  for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL((probe<VAR, HELP, PM>), dim3(256), dim3(512), 0, 0, d, b, x, l, cyc, iters);
   hipDeviceSynchronize();
   std::vector<float> xh(256 * 16), lh(256);
   std::vector<long long> ch(1024);
@@ -110,5 +144,11 @@ int main() {
   run<2, 0>("asm fmac_dpp, alone", d, b, x, l, cyc, xr, lr);
   run<1, 12>("compiler dpp, + MFMA wave", d, b, x, l, cyc, xr, lr);
   run<2, 9>("asm fmac_dpp, + MFMA wave", d, b, x, l, cyc, xr, lr);
+  run<2, 40, 1>("asm fmac_dpp, + LDS-read wave", d, b, x, l, cyc, xr, lr);
+  run<2, 3, 2>("asm fmac_dpp, + panel-mix wave", d, b, x, l, cyc, xr, lr);
+  run<2, 3, 3>("asm fmac_dpp, + MFMA 20 regs", d, b, x, l, cyc, xr, lr);
+  run<2, 3, 4>("asm fmac_dpp, + reads, MFMA indep", d, b, x, l, cyc, xr, lr);
+  run<2, 2, 2>("asm fmac_dpp, + panel-mix x2/leaf", d, b, x, l, cyc, xr, lr);
+  run<2, 1, 2>("asm fmac_dpp, + panel-mix x1/leaf", d, b, x, l, cyc, xr, lr);
   return 0;
 }
