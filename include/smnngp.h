@@ -223,11 +223,14 @@ int smn_spr_loss_grad(smn_ctx* ctx, int dtype, int net, int act, int num_hiddens
 /* ---- multi-GPU (nothing in the reference to mirror) ----
  * One process per GPU.  Rank 0 calls smn_comm_unique_id and ships the 128 bytes to the other
  * ranks by any host channel; every rank then calls smn_comm_init.  smn_allgather is an RCCL
- * all-gather of `count` elements per rank on the context's stream. */
+ * all-gather of `count` elements per rank on the context's stream; the caller states the world it
+ * believes it is in: SMN_ECOMM when that is not the communicator's size (a context without a
+ * communicator is a world of one, where the gather is a copy) -- a world > 1 call can never quietly
+ * gather nothing. */
 int smn_comm_unique_id(char id_out[128]);
 int smn_comm_init(smn_ctx* ctx, int nranks, int rank, const char id[128]);
 int smn_comm_destroy(smn_ctx* ctx);
-int smn_allgather(smn_ctx* ctx, int dtype, const void* send_d, void* recv_d, int64_t count);
+int smn_allgather(smn_ctx* ctx, int nranks, int dtype, const void* send_d, void* recv_d, int64_t count);
 /* Paired lower-trapezoid layout (host side: sharding.py).  The n rows are cut into 2*nranks blocks
  * of block_rows rows (a multiple of 128); rank r owns blocks r and 2*nranks-1-r and packs block b
  * densely as block_rows rows of leading dimension (b+1)*block_rows, low block first, so every rank

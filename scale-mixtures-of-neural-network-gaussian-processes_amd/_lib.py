@@ -82,7 +82,7 @@ PROTOTYPES = {
     "smn_spr_loss_grad": [_vp, _i, _i, _i, _i, _d, _d, _d, _vp, _i64, _i64, _i64, _vp, _d, _d, _d, _pd, _pd, _pi, _pd],
     "smn_comm_init": [_vp, _i, _i, C.c_char_p],
     "smn_comm_destroy": [_vp],
-    "smn_allgather": [_vp, _i, _vp, _vp, _i64],
+    "smn_allgather": [_vp, _i, _i, _vp, _vp, _i64],
     "smn_unpack_lower_blocks": [_vp, _i, _vp, _i64, _i, _i64, _vp, _i64],
     "smn_lml_from_blocks": [_vp, _i, _vp, _i64, _i, _i64, _vp, _d, _d, _d, _pd, _pd, _pd, _pi],
     "smn_comm_info": [_vp, _pi, _pi],

@@ -25,6 +25,17 @@ def _newer(src_list, target):
     return any(os.path.getmtime(s) > t for s in src_list)
 
 
+def stale_sources(variant=""):
+    """Names of the sources / headers / includes newer than the built library (all of them when it does not exist)."""
+    lib = os.path.join(HERE, "libsmnngp%s.so" % ("_" + variant if variant else ""))
+    deps = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".hpp", ".inc"))]
+    deps.append(os.path.join(HERE, "..", "include", "smnngp.h"))
+    if not os.path.exists(lib):
+        return [os.path.basename(d) for d in deps]
+    t = os.path.getmtime(lib)
+    return [os.path.basename(d) for d in deps if os.path.getmtime(d) > t]
+
+
 def build(force=False, verbose=False, variant="", defines=()):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     suffix = "_" + variant if variant else ""

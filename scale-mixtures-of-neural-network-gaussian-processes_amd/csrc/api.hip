@@ -13,7 +13,9 @@ int smn_allow_lds(smn_ctx* ctx, const void* kernel, size_t lds) {
 
 int smn_workspace(smn_ctx* ctx, int slot, size_t bytes, void** out) {
   if (slot < 0 || slot >= smn_ctx::kSlots) return smn_fail(ctx, SMN_EINVAL, "bad workspace slot");
+  if (slot == 0) ctx->op_x = nullptr;   // whoever asks for slot 0 is about to overwrite the padded operand
   if (ctx->ws_bytes[slot] < bytes) {
+    if (slot == 2) ctx->shard_a = nullptr;   // a pipelined exchange in flight must not scatter into the freed buffer
     if (ctx->ws[slot]) {
       if (ctx->stream_comm) SMN_HIP(ctx, hipStreamSynchronize(ctx->stream_comm));
       SMN_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -263,14 +265,10 @@ extern "C" int smn_ctx_create(int device_id, smn_ctx** out) {
   if (const char* e = getenv("SMN_REC_SYM")) c->rec_sym = e[0] != '0';
   if (const char* e = getenv("SMN_CNN_TILED")) c->cnn_tiled = atoi(e);
   if (const char* e = getenv("SMN_CNN_FAST32")) c->cnn_fast32 = atoi(e);
-  if (const char* e = getenv("SMN_PERSIST_MAXK")) c->persist_max_k = atoi(e);
-  if (const char* e = getenv("SMN_HALF_TILES")) c->half_tile_max = atoi(e);
-  if (const char* e = getenv("SMN_QUARTER_TILES")) c->quarter_tile_max = atoi(e);
   if (const char* e = getenv("SMN_SUPER")) c->super_panel = atol(e);
   if (const char* e = getenv("SMN_SUPER_WIDE")) c->super_panel_wide = atol(e);
   if (const char* e = getenv("SMN_SUPER_WIDE_ROWS")) c->super_wide_rows = atol(e);
-  if (const char* e = getenv("SMN_PANEL_SMALL")) c->panel_small_rows = atoi(e);
-  if (const char* e = getenv("SMN_PANEL_HELPERS")) c->panel_helpers = atoi(e);
+  if (const char* e = getenv("SMN_PANEL_LEAF")) c->panel_leaf = e[0] != '0';
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0)

@@ -17,9 +17,11 @@
 //                  (a true TRSM, no explicit inverse): 16-column blocks are brought up to date with MFMAs
 //                  straight from the LDS image, 8-column micro-panels are factored in registers.
 //                  Workgroup 0 stores L_kk (to a side buffer), sum(log pivots) and the info flag.
-//   panelh_kernel  the form the factorisation launches (round 2): the same row threads, with the MFMA block updates
-//                  on a second set of waves that runs one 16-column block ahead (same bits; panel_kernel stays for
-//                  the solve-only sweep of smn_trsm and for A/B, SMN_PANEL_HELPERS=0).
+//   panelr_kernel  the form the factorisation launches (round 3): the micro-panels are replaced by a register-resident
+//                  16x16 leaf (panel_leaf.hpp: factor + TRSM of the lane's own row through DPP broadcasts), the block
+//                  updates run on all waves behind each leaf, the image streams in beside the first leaves and the
+//                  solved columns leave as they finish.  panel_kernel stays for the solve-only sweep of smn_trsm and
+//                  for A/B (SMN_PANEL_LEAF=0).
 //   update_kernel  C -= A B^T on the f32/f64 MFMA (gemm_nt.hpp), four uses:
 //     strip   the 128 columns in front of the second sub-panel (K = 128);
 //     near    after an outer panel, the columns of ITS super-panel only (K = 256, a lower trapezoid);
@@ -49,6 +51,11 @@ namespace {
 
 constexpr int PB = 128;  // sub-panel width == diagonal block edge == GEMM tile edge
 constexpr int MP = 8;    // micro-panel width of the in-LDS factorisation
+// Launch-shape thresholds (round-1/2 run-time knobs; the final sweeps were flat around these values: profiles/r02_knob_sweep_final.txt)
+constexpr int kQuarterTileMax = 256;   // update launches of at most this many 128x128 tiles use 64x64 tiles
+constexpr int kHalfTileMax = 384;      // ... and of at most this many, 64-row tiles
+constexpr int kPersistMaxK = 512;      // largest K the persistent trailing kernel takes
+constexpr int kPanelSmallRows = 4096;  // f32 panels with at most this many rows below use 64-row workgroups
 
 template <typename T>
 struct PanelCfg;
@@ -142,6 +149,8 @@ __device__ __forceinline__ double rsqrt_t(double x) { return 1.0 / sqrt(x); }
 //      triangular solve on its own 8 values (for a pivot row this reproduces its row of L,
 //      diagonal included: d * rsqrt(d) = sqrt(d)); writes them back; barrier.
 // 2 barriers per micro-panel (32 per sub-panel, + 7 for the MFMA blocks) instead of 2 per column.
+// (Round 2's panelh_kernel -- these row threads with the MFMA block updates on a second set of waves one block ahead,
+// 27 us per sub-panel against 29 -- is superseded by panelr_kernel below and gone from the source: profiles/r02_panel_helpers_ab.txt.)
 // prefactored != 0: the diagonal block already holds L (solve only; used by smn_trsm).
 // XRV = rows below the diagonal block carried per workgroup.  The default (128 in f32) minimises the number of
 // workgroups that each redo the diagonal factorisation; the f32 64-row form is launched when the panel has few
@@ -365,246 +374,6 @@ __global__ void __launch_bounds__(panel_threads(XRV)) panel_kernel(T* __restrict
     printf("panel wg%d (100 MHz ticks): stage_in %lld  mfma_blocks %lld  dots %lld  factor+solve %lld  store %lld\n",
            (int)blockIdx.x, pt_acc[0], pt_acc[1], pt_acc[2], pt_acc[3], pt_acc[4]);
 #endif
-}
-
-// panelh_kernel — panel_kernel with the MFMA block updates moved onto a second set of waves (round 2).
-// In panel_kernel the 16-column block updates (9.5 of its 27 us) and the per-row micro-panel phases (VALU / LDS latency)
-// alternate in the same waves, one wave per SIMD.  Here waves [0, NW) are the row threads exactly as before, minus the
-// block updates; waves [NW, 2 NW) ("helpers", the second wave of every SIMD) bring the NEXT 16-column block up to date
-// while the row threads work on the current one: the part of that update that needs only finished columns (K = 0 .. cb)
-// runs in four chunks between the row threads' four barriers of the block, only its last 16 columns (the block just
-// finished) are left for the boundary.  Same tiles per wave, same K order per accumulator: the same bits as panel_kernel.
-// Factor mode only (smn_trsm's solve-only sweep keeps panel_kernel).
-template <typename T, int XRV = PanelCfg<T>::XR>
-__global__ void __launch_bounds__(2 * panel_threads(XRV)) panelh_kernel(T* __restrict__ a, int64_t lda, int64_t j0,
-                                                                          int64_t rbeg, int64_t n_total,
-                                                                          double* __restrict__ logdet,
-                                                                          int* __restrict__ info, T* __restrict__ ldiag_out,
-                                                                          int64_t id0, int64_t id1) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int XR = XRV, NTV = panel_threads(XRV), NT = 2 * NTV, LD = PanelCfg<T>::LD;
-  constexpr int VEC = 16 / sizeof(T);
-  using vec_t = typename Mfma<T>::vec_t;
-  T* S = reinterpret_cast<T*>(smem);        // [PB + XR][LD]
-  T* blk = S + (PB + XR) * LD;              // [MP][MP] staging of the diagonal micro-block
-  T* piv = blk + MP * MP;                   // [PB] pivots
-  const int tid = threadIdx.x;
-  const int64_t rb = rbeg + (int64_t)blockIdx.x * XR;
-  if (id0 >= 0 && rb >= id0 && rb + XR <= id1 && rb - id0 >= j0 + PB) return;
-  const int nx = (int)max((int64_t)0, min((int64_t)XR, n_total - rb));
-  constexpr int RV = PB / VEC;
-  {
-    // global -> LDS, all 2 NTV threads; both blocks' loads of a thread are in flight before its first LDS write
-    constexpr int ND = PB * RV, SID = (ND + NT - 1) / NT, SIX = (XR * RV + NT - 1) / NT;
-    vec_t td[SID], tx[SIX];
-#pragma unroll
-    for (int u = 0; u < SID; ++u) {
-      const int idx = u * NT + tid;
-      if (idx < ND) td[u] = *reinterpret_cast<const vec_t*>(&a[(j0 + idx / RV) * lda + j0 + (idx % RV) * VEC]);
-    }
-#pragma unroll
-    for (int u = 0; u < SIX; ++u) {
-      const int idx = u * NT + tid;
-      if (idx < nx * RV) tx[u] = *reinterpret_cast<const vec_t*>(&a[(rb + idx / RV) * lda + j0 + (idx % RV) * VEC]);
-    }
-#pragma unroll
-    for (int u = 0; u < SID; ++u) {
-      const int idx = u * NT + tid;
-      if (idx < ND) *reinterpret_cast<vec_t*>(&S[(idx / RV) * LD + (idx % RV) * VEC]) = td[u];
-    }
-#pragma unroll
-    for (int u = 0; u < SIX; ++u) {
-      const int idx = u * NT + tid;
-      if (idx < nx * RV) *reinterpret_cast<vec_t*>(&S[(PB + idx / RV) * LD + (idx % RV) * VEC]) = tx[u];
-    }
-  }
-  PT_DECL;
-  __syncthreads();
-  PT_MARK(0);
-
-  using M = PanelMma<T>;
-  constexpr int CB = 16;
-  constexpr int NW = NTV / 64;
-  constexpr int RT = (PB + XR) / M::TM;
-  constexpr int TPW = (RT + NW - 1) / NW;
-  static_assert(RT % NW == 0 && TPW <= 4, "tile split over the helper waves");
-  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  if (wave >= NW) {
-    // ------------------------------------------------------------ helpers: the next block's update, one block ahead
-    const int hw = wave - NW;
-    const int fr = M::frag_row(lane), fk = M::frag_k(lane);
-    typename M::acc_t acc[TPW];
-    auto init = [&](auto u0c, int cn) {
-      constexpr int U0 = decltype(u0c)::value;
-#pragma unroll
-      for (int u = U0; u < TPW; ++u) {
-        const int rt = (hw + u * NW) * M::TM;
-#pragma unroll
-        for (int i = 0; i < M::ACC; ++i) acc[u][i] = -S[(rt + M::acc_row(lane, i)) * LD + cn + M::acc_col(lane)];
-      }
-    };
-    auto accumulate = [&](auto u0c, int cn, int k0, int k1) {   // K columns [k0, k1) of the update of columns [cn, cn+16)
-      constexpr int U0 = decltype(u0c)::value;
-      if constexpr (U0 < TPW) {
-        const T* pb = &S[(cn + fr) * LD + fk];
-        const T* pa = &S[(hw * M::TM + fr) * LD + fk];
-        for (int kb = k0; kb < k1; kb += M::KSTEP) {
-          const typename M::vec_t bv = *reinterpret_cast<const typename M::vec_t*>(pb + kb);
-          typename M::vec_t av[TPW];
-#pragma unroll
-          for (int u = U0; u < TPW; ++u)
-            av[u] = *reinterpret_cast<const typename M::vec_t*>(pa + u * NW * M::TM * LD + kb);
-#pragma unroll
-          for (int i = 0; i < M::NK; ++i)
-#pragma unroll
-            for (int u = U0; u < TPW; ++u) M::mma1(acc[u], av[u][i], bv[i]);
-        }
-      }
-    };
-    auto store = [&](auto u0c, int cn) {
-      constexpr int U0 = decltype(u0c)::value;
-#pragma unroll
-      for (int u = U0; u < TPW; ++u) {
-        const int rt = (hw + u * NW) * M::TM;
-#pragma unroll
-        for (int i = 0; i < M::ACC; ++i) S[(rt + M::acc_row(lane, i)) * LD + cn + M::acc_col(lane)] = -acc[u][i];
-      }
-    };
-    auto with_u0 = [&](int u0, auto&& f) {
-      switch (u0) {
-        case 0: f(std::integral_constant<int, 0>{}); break;
-        case 1: f(std::integral_constant<int, 1>{}); break;
-        case 2: f(std::integral_constant<int, 2>{}); break;
-        case 3: f(std::integral_constant<int, 3>{}); break;
-        default: break;
-      }
-    };
-    for (int cb = 0; cb < PB; cb += CB) {
-      const int cn = cb + CB;                       // the block being brought up to date
-      const bool nb = cn < PB;
-      const int first = cn / M::TM;                 // tiles above row cn are finished rows
-      const int u0 = first <= hw ? 0 : (first - hw + NW - 1) / NW;
-      const int jb = cb / CB;                       // finished 16-column blocks in front of the current one
-      if (nb) with_u0(u0, [&](auto c) { init(c, cn); });
-#pragma unroll 1
-      for (int q = 0; q < 4; ++q) {
-        if (nb) {
-          const int k0 = (jb * q / 4) * CB, k1 = (jb * (q + 1) / 4) * CB;
-          if (k1 > k0) with_u0(u0, [&](auto c) { accumulate(c, cn, k0, k1); });
-        }
-        __syncthreads();
-      }
-      if (nb) {
-        with_u0(u0, [&](auto c) {
-          accumulate(c, cn, cb, cn);                // the block the row threads have just finished
-          store(c, cn);
-        });
-        __syncthreads();
-      }
-    }
-  } else {
-    // ------------------------------------------------------------ row threads: panel_kernel's micro-panel phases
-    const int row = tid;
-    const bool active = row < PB + nx;
-    for (int c0 = 0; c0 < PB; c0 += MP) {
-      const int cb = c0 & ~(CB - 1);
-      const bool work = active && row >= c0;
-      T v[MP];
-      if (work) {
-#pragma unroll
-        for (int q = 0; q < MP; q += VEC) {
-          const vec_t t = *reinterpret_cast<const vec_t*>(&S[row * LD + c0 + q]);
-#pragma unroll
-          for (int e = 0; e < VEC; ++e) v[q + e] = t[e];
-        }
-        for (int k = cb; k < c0; k += VEC) {
-          const vec_t av = *reinterpret_cast<const vec_t*>(&S[row * LD + k]);
-#pragma unroll
-          for (int q = 0; q < MP; ++q) {
-            const vec_t bv = *reinterpret_cast<const vec_t*>(&S[(c0 + q) * LD + k]);
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) v[q] = fma(-av[e], bv[e], v[q]);
-          }
-        }
-        if (row < c0 + MP) {
-#pragma unroll
-          for (int q = 0; q < MP; ++q) blk[(row - c0) * MP + q] = v[q];
-        }
-      }
-      PT_MARK(1);
-      __syncthreads();
-      PT_MARK(2);
-      if (work) {
-        T lm[MP][MP], rinv[MP];
-#pragma unroll
-        for (int i = 0; i < MP; ++i)
-#pragma unroll
-          for (int j = 0; j <= i; ++j) lm[i][j] = blk[i * MP + j];
-#pragma unroll
-        for (int j = 0; j < MP; ++j) {
-          const T d = lm[j][j];
-          if (row == PB - 1) piv[c0 + j] = d;
-          rinv[j] = rsqrt_t(d);
-#pragma unroll
-          for (int i = j + 1; i < MP; ++i) lm[i][j] *= rinv[j];
-#pragma unroll
-          for (int i = j + 1; i < MP; ++i)
-#pragma unroll
-            for (int jj = j + 1; jj <= i; ++jj) lm[i][jj] = fma(-lm[i][j], lm[jj][j], lm[i][jj]);
-        }
-#pragma unroll
-        for (int j = 0; j < MP; ++j) {
-          T x = v[j];
-#pragma unroll
-          for (int jj = 0; jj < j; ++jj) x = fma(-v[jj], lm[j][jj], x);
-          v[j] = x * rinv[j];
-        }
-#pragma unroll
-        for (int q = 0; q < MP; q += VEC) {
-          vec_t t;
-#pragma unroll
-          for (int e = 0; e < VEC; ++e) t[e] = v[q + e];
-          *reinterpret_cast<vec_t*>(&S[row * LD + c0 + q]) = t;
-        }
-      }
-      PT_MARK(3);
-      __syncthreads();
-      PT_MARK(4);
-      if (c0 + MP == cb + CB && cb + CB < PB) __syncthreads();   // the helpers' last 16 columns + store of the next block
-      PT_MARK(5);
-    }
-#ifdef SMN_PANEL_TIMING
-    if (tid == 0 && j0 == 0 && blockIdx.x == 0)
-      printf("panelh wg0 row wave (100 MHz ticks): stage_in %lld  dots %lld  wait_A %lld  factor+solve %lld  wait_B %lld  boundary %lld\n",
-             pt_acc[0], pt_acc[1], pt_acc[2], pt_acc[3], pt_acc[4], pt_acc[5]);
-#endif
-  }
-  __syncthreads();
-
-  if (blockIdx.x == 0) {
-    if (tid < 64) {
-      const T d0 = piv[tid], d1 = piv[tid + 64];
-      double lg = log((double)d0) + log((double)d1);
-      int bad = !(d0 > T(0)) ? tid : (!(d1 > T(0)) ? tid + 64 : INT_MAX);
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        lg += __shfl_xor(lg, o);
-        bad = min(bad, __shfl_xor(bad, o));
-      }
-      if (tid == 0) {
-        atomicAdd(logdet, lg);
-        if (bad != INT_MAX) atomicMin(info, (int)(j0 + bad + 1));
-      }
-    }
-    for (int idx = tid; idx < PB * RV; idx += NT) {   // L_kk to the side buffer (see panel_kernel)
-      const int r = idx / RV, c = (idx % RV) * VEC;
-      *reinterpret_cast<vec_t*>(&ldiag_out[r * PB + c]) = *reinterpret_cast<const vec_t*>(&S[r * LD + c]);
-    }
-  }
-  for (int idx = tid; idx < nx * RV; idx += NT) {
-    const int r = idx / RV, c = (idx % RV) * VEC;
-    *reinterpret_cast<vec_t*>(&a[(rb + r) * lda + j0 + c]) = *reinterpret_cast<const vec_t*>(&S[(PB + r) * LD + c]);
-  }
 }
 
 // panelr_kernel — the form the factorisation launches from round 3 on: the 8-column in-LDS micro-panels are replaced by
@@ -1015,12 +784,7 @@ __global__ void __launch_bounds__(256, BN == 64 ? 4 : (BM == 64 ? (sizeof(T) == 
         t.acc[m][n][i] = -u.a[gr * u.lda + gc];
       }
   // trailing updates (TAG 1) run K = 256 ... 1024: the pipelined K loop; strips (K = 128) the plain one
-#ifdef SMN_DEBUG_SAMEPANEL   // timing experiment only (WRONG results): every tile reads one of 8 operand panels, so all hit L2
-  t.template mainloop<TAG == 1 ? 1 : 0>(u.a + (u.r0 + (row0 - u.r0) % 1024) * u.lda + u.k0, u.lda,
-                                        u.a + (u.c0 + (col0 - u.c0) % 1024) * u.lda + u.k0, u.lda, u.K, smem);
-#else
   t.template mainloop<TAG == 1 ? 1 : 0>(u.a + row0 * u.lda + u.k0, u.lda, u.a + col0 * u.lda + u.k0, u.lda, u.K, smem);
-#endif
 #pragma unroll
   for (int m = 0; m < Tile::MT; ++m)
 #pragma unroll
@@ -1190,7 +954,7 @@ int launch_update(smn_ctx* ctx, hipStream_t st, T* a, int64_t lda, int64_t r0, i
   if constexpr (sizeof(T) == 4) {
     // CUs this stream may use: the bulk stream of the look-ahead is masked off the chain's CUs
     const int cus = (st == ctx->stream_bulk && st != nullptr) ? ctx->num_cu - ctx->chain_cus : ctx->num_cu;
-    if (tag == 1 && lower && !u.use_map && ctx->persistent_trail && nt > 2 * cus && K <= ctx->persist_max_k &&
+    if (tag == 1 && lower && !u.use_map && ctx->persistent_trail && nt > 2 * cus && K <= kPersistMaxK &&
         ctx->chol_id0 < 0) {   // the persistent walk has no tile skipping
       // persistent walk over the lower tiles, two workgroups per CU
       const size_t plds = TileNT<T, kTile, kTile, 2>::LDS_BYTES;
@@ -1200,7 +964,7 @@ int launch_update(smn_ctx* ctx, hipStream_t st, T* a, int64_t lda, int64_t r0, i
       return SMN_OK;
     }
   }
-  if (!u.use_map && nt <= ctx->quarter_tile_max) {
+  if (!u.use_map && nt <= kQuarterTileMax) {
     // very few tiles (strips; near / F0 updates of the chain-bound tail): 64x64 tiles, four workgroups per tile
     ProfScope ps(ctx, tag ? PROF_TRAIL : PROF_STRIP, st);
     constexpr size_t qlds = TileNT<T, 64, 64, SMN_STAGES>::LDS_BYTES;
@@ -1214,7 +978,7 @@ int launch_update(smn_ctx* ctx, hipStream_t st, T* a, int64_t lda, int64_t r0, i
     SMN_CHECK_LAUNCH(ctx);
     return SMN_OK;
   }
-  if (!u.use_map && nt <= ctx->half_tile_max) {
+  if (!u.use_map && nt <= kHalfTileMax) {
     // too few 128x128 tiles to fill the chip: 64-row tiles, twice as many workgroups
     const int64_t nh = lower == 1   ? tiles_m * (tiles_m + 1)
                        : lower == 2 ? tiles_n * (tiles_n + 1) + 2 * (tiles_m - tiles_n) * tiles_n
@@ -1250,20 +1014,11 @@ int launch_panel_x(smn_ctx* ctx, hipStream_t st, T* a, int64_t lda, int64_t j0, 
   const int64_t rbeg = j0 + PB;
   const int64_t below = n_total - rbeg;
   const unsigned grid = below > 0 ? (unsigned)((below + XRV - 1) / XRV) : 1u;
-  if (ctx->panel_helpers >= 2 && !prefactored) {
+  if (ctx->panel_leaf && !prefactored) {
     ProfScope ps(ctx, PROF_PANEL, st);
     T* ldiag = reinterpret_cast<T*>(ctx->ws[3]) + (j0 / PB) * (int64_t)(PB * PB);
     auto kernr = panelr_kernel<T, XRV>;
     hipLaunchKernelGGL(kernr, dim3(grid), dim3(2 * panel_threads(XRV)), panelr_lds_bytes<T>(XRV), st, a, lda, j0, rbeg, n_total,
-                       ctx->d_scal, ctx->d_info, ldiag, ctx->chol_id0, ctx->chol_id1);
-    SMN_CHECK_LAUNCH(ctx);
-    return SMN_OK;
-  }
-  if (ctx->panel_helpers && !prefactored) {
-    ProfScope ps(ctx, PROF_PANEL, st);
-    T* ldiag = reinterpret_cast<T*>(ctx->ws[3]) + (j0 / PB) * (int64_t)(PB * PB);
-    auto kernh = panelh_kernel<T, XRV>;
-    hipLaunchKernelGGL(kernh, dim3(grid), dim3(2 * panel_threads(XRV)), panel_lds_bytes<T>(XRV), st, a, lda, j0, rbeg, n_total,
                        ctx->d_scal, ctx->d_info, ldiag, ctx->chol_id0, ctx->chol_id1);
     SMN_CHECK_LAUNCH(ctx);
     return SMN_OK;
@@ -1283,7 +1038,7 @@ template <typename T>
 int launch_panel(smn_ctx* ctx, hipStream_t st, T* a, int64_t lda, int64_t j0, int64_t n_total, int prefactored) {
   if constexpr (sizeof(T) == 4 && PanelCfg<T>::XR == 128) {
     // few row blocks left: 64-row workgroups (twice as many, each with a quarter less MFMA work)
-    if (n_total - (j0 + PB) <= (int64_t)ctx->panel_small_rows) return launch_panel_x<T, 64>(ctx, st, a, lda, j0, n_total, prefactored);
+    if (n_total - (j0 + PB) <= (int64_t)kPanelSmallRows) return launch_panel_x<T, 64>(ctx, st, a, lda, j0, n_total, prefactored);
   }
   return launch_panel_x<T, PanelCfg<T>::XR>(ctx, st, a, lda, j0, n_total, prefactored);
 }
@@ -1297,11 +1052,6 @@ int set_lds_attrs(smn_ctx* ctx) {
                                    (int)panel_lds_bytes<T>()));
   if constexpr (sizeof(T) == 4 && PanelCfg<T>::XR == 128)
     SMN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(panel_kernel<T, 64>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)panel_lds_bytes<T>(64)));
-  SMN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(panelh_kernel<T>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)panel_lds_bytes<T>()));
-  if constexpr (sizeof(T) == 4 && PanelCfg<T>::XR == 128)
-    SMN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(panelh_kernel<T, 64>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)panel_lds_bytes<T>(64)));
   SMN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(panelr_kernel<T>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)panelr_lds_bytes<T>()));

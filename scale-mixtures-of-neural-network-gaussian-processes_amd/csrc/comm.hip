@@ -129,10 +129,13 @@ int allgather_on(smn_ctx* ctx, hipStream_t st, int dtype, const void* send_d, vo
 }
 }  // namespace
 
-extern "C" int smn_allgather(smn_ctx* ctx, int dtype, const void* send_d, void* recv_d, int64_t count) {
+extern "C" int smn_allgather(smn_ctx* ctx, int nranks, int dtype, const void* send_d, void* recv_d, int64_t count) {
   if (!ctx || !send_d || !recv_d || count <= 0) return SMN_EINVAL;
   SMN_ENTER(ctx);
   if (dtype != SMN_F32 && dtype != SMN_F64) return smn_fail(ctx, SMN_EINVAL, "bad dtype");
+  const int P = ctx->comm ? ctx->nranks : 1;
+  if (nranks != P)
+    return smn_fail(ctx, SMN_ECOMM, "smn_allgather: %d ranks asked for, the context's communicator has %d", nranks, P);
   ProfScope ps(ctx, PROF_COMM, ctx->stream);
   return allgather_on(ctx, ctx->stream, dtype, send_d, recv_d, count);
 }

@@ -26,6 +26,9 @@ struct smn_ctx {
   hipEvent_t ev_c0 = nullptr, ev_c1 = nullptr;   // main -> comm (piece built), comm -> main (all pieces scattered)
   // factorisation workspace prepared by smn_shard_begin for the pipelined exchange (slot 2)
   void* shard_a = nullptr; int64_t shard_lda = 0, shard_n = 0; int shard_dtype = -1;
+  // which x the padded operand in slot 0 was made from (smn_kernel_mlp_shard_rows with reuse_operand); any other request
+  // for slot 0 clears it
+  const void* op_x = nullptr; int64_t op_n = 0, op_d = 0, op_ldx = 0; int op_dtype = -1;
   std::string err;
   // cached workspace arenas (grown on demand, freed with the context)
   static constexpr int kSlots = 10;
@@ -57,11 +60,7 @@ struct smn_ctx {
   bool chol_prepped = false;         // the caller has shifted the diagonal and reset logdet / info already (aug_prep)
   std::unordered_map<const void*, size_t> max_lds;   // largest dynamic-LDS size already allowed per kernel (smn_allow_lds)
   bool lds_attrs_done[2] = {false, false};   // hipFuncSetAttribute(MaxDynamicSharedMemorySize) issued for f32 / f64 kernels
-  int panel_helpers = 2;             // panel kernel of the factorisation: 2 panelr_kernel (register leaf), 1 panelh_kernel, 0 panel_kernel (env SMN_PANEL_HELPERS)
-  int panel_small_rows = 4096;       // f32 panels with at most this many rows below use 64-row workgroups (env SMN_PANEL_SMALL)
-  int quarter_tile_max = 256;        // update launches with at most this many 128x128 tiles use 64x64 tiles (env SMN_QUARTER_TILES)
-  int half_tile_max = 384;           // ... and with at most this many, 64-row tiles (env SMN_HALF_TILES)
-  int persist_max_k = 512;           // largest K the persistent trailing kernel takes (env SMN_PERSIST_MAXK)
+  bool panel_leaf = true;            // panelr_kernel (register-resident 16x16 leaf) in the factorisation; env SMN_PANEL_LEAF=0: panel_kernel
   int cnn_fast32 = 1;                // conv-NNGP: register-only 3x3 stencil for 32x32 images (env SMN_CNN_FAST32: 0 never, 1 fp64 only, 2 both)
   int cnn_tiled = 1;                 // conv-NNGP pair kernel: XCD-tiled pair order for large problems (env SMN_CNN_TILED: 0 never, 2 always)
   bool rec_sym = true;               // stand-alone recursion: lower-tile + mirror kernel when symmetric (env SMN_REC_SYM=0)

@@ -2,7 +2,7 @@
 //
 // Computes a BM x BN block of  A[M,K] * B[N,K]^T  (both operands row-major, K contiguous: the
 // "NT" form, which is what X X^T, P P^T and B L^-T all are) with the exact-f32 MFMA
-// v_mfma_f32_16x16x4_f32 (round 2; v_mfma_f32_32x32x2_f32 before: see Mfma<float>) or the f64 MFMA v_mfma_f64_16x16x4_f64.  256 threads = 4 waves in a
+// v_mfma_f32_16x16x4_f32 or the f64 MFMA v_mfma_f64_16x16x4_f64.  256 threads = 4 waves in a
 // 2x2 arrangement; each wave owns a (BM/2) x (BN/2) sub-block in accumulator registers.
 //
 // LDS image: one 128-byte row per matrix row per K-step (32 f32 / 16 f64), 16-byte chunks
@@ -28,10 +28,6 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 template <typename T>
 struct Mfma;
 
-#ifndef SMN_F32_MFMA16
-#define SMN_F32_MFMA16 1   // 0: the r01 engine on v_mfma_f32_32x32x2_f32 (A/B builds)
-#endif
-#if SMN_F32_MFMA16
 // v_mfma_f32_16x16x4_f32: the same 64 flop/cycle/SIMD as the 32x32x2 form, but an accumulator register is rewritten every
 // 4 k instead of every 2: half the accumulator traffic on the SIMD's VGPR ports, which the 32x32x2 form saturates by itself
 // (every LDS / global-load return then steals MFMA cycles: scratch/r02/tile_probe, profiles/r02_tile_probe.txt).
@@ -53,29 +49,6 @@ struct Mfma<float> {
   static __device__ __forceinline__ int acc_row(int lane, int i) { return 4 * (lane >> 4) + i; }
   static __device__ __forceinline__ int acc_col(int lane) { return lane & 15; }
 };
-#else
-template <>
-struct Mfma<float> {
-  static constexpr int TM = 32, TN = 32;  // MFMA output tile
-  static constexpr int ACC = 16;          // accumulator elements per lane per tile
-  static constexpr int BK = 32;           // elements per 128-byte LDS row (one K-step)
-  static constexpr int VEC = 4;           // elements per 16-byte chunk
-  static constexpr int KG = 4;            // fragment reads per K-step
-  using acc_t = f32x16;
-  using vec_t = f32x4;
-  static __device__ __forceinline__ int frag_row(int lane) { return lane & 31; }
-  static __device__ __forceinline__ int frag_chunk(int lane, int g) { return 2 * g + (lane >> 5); }
-  static __device__ __forceinline__ void mma(acc_t& c, const vec_t& a, const vec_t& b) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[i], c, 0, 0, 0);
-  }
-  // C/D map of the 32x32 f32 accumulator (cdna_hip_programming.md section 3)
-  static __device__ __forceinline__ int acc_row(int lane, int i) {
-    return (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
-  }
-  static __device__ __forceinline__ int acc_col(int lane) { return lane & 31; }
-};
-#endif
 
 template <>
 struct Mfma<double> {
@@ -161,34 +134,10 @@ struct TileNT {
   //                    issued all its reads of this one, the last group's fragments are already in registers, so the
   //                    MFMAs start at once and the first fragments of the NEXT step + the global loads of the step after
   //                    it ride under them.
-  // Same arithmetic in the same order as the plain loop (SMN_PIPE=0 keeps that one for A/B): identical bits.
-#ifndef SMN_PIPE
-#define SMN_PIPE 1
-#endif
-#ifndef SMN_GLOAD_EARLY
-#define SMN_GLOAD_EARLY 1   // 0: the r01 placement (behind the barrier), for A/B
-#endif
-#ifndef SMN_WRITE_GROUP
-#define SMN_WRITE_GROUP 1
-#endif
-// Timing probes of the pipelined loop (scratch/r02/tile_probe): each drops one ingredient.  WRONG results, never set in the library.
-#ifndef SMN_PROBE_NO_BARRIER
-#define SMN_PROBE_NO_BARRIER 0
-#endif
-#ifndef SMN_PROBE_NO_GLOAD
-#define SMN_PROBE_NO_GLOAD 0
-#endif
-#ifndef SMN_PROBE_NO_SWRITE
-#define SMN_PROBE_NO_SWRITE 0
-#endif
-#ifndef SMN_PROBE_NO_FRAG
-#define SMN_PROBE_NO_FRAG 0
-#endif
-  // SMN_PIPE_F64_BIG=1: the f64 128x128 tile takes the pipelined loop too -- it spills 164 B inside the loop and the fp64
-  // N=8192 step goes 12.37 -> 12.75 ms (scratch/f64big_ab.sh), so it stays on the plain loop.
-#ifndef SMN_PIPE_F64_BIG
-#define SMN_PIPE_F64_BIG 0
-#endif
+  // Same arithmetic in the same order as the plain loop: identical bits.  (Round-2 A/B switches -- the 32x32x2 MFMA form,
+  // the un-pipelined loop, later global loads, a later staging-write group, the f64 128x128 tile on the pipelined loop
+  // (it spills) and the timing probes that each dropped one ingredient -- are gone from the source; their measurements are
+  // profiles/r02_tile_probe.txt, r02_mfma16_ab.txt, r02_gload_placement_ab.txt, r01f_pipelined_kloop_ab.txt.)
   __device__ __forceinline__ void frag_load(const char* stage, int g, int lane, int wr, int wc, vec_t (&a)[MT], vec_t (&b)[NT]) {
     const char* sa = stage + (wr * WM) * ROWB;
     const char* sb = stage + A_BYTES + (wc * WN) * ROWB;
@@ -229,10 +178,10 @@ struct TileNT {
     __syncthreads();
 
     // (the f64 128x128 tile has no registers left for a second fragment set: it keeps the plain loop)
-    constexpr bool can_pipe = SMN_PIPE && MODE != 0 && STAGES == 2 && M::KG >= 2 && !(SMN_PIPE_F64_BIG == 0 && sizeof(T) == 8 && MT * NT >= 16);
+    constexpr bool can_pipe = MODE != 0 && STAGES == 2 && M::KG >= 2 && !(sizeof(T) == 8 && MT * NT >= 16);
     if (can_pipe && (MODE == 1 ? nk >= 1 : nk >= 8)) {
       constexpr int KG = M::KG;
-      constexpr int WG = KG >= 4 ? SMN_WRITE_GROUP : 0;             // group whose MFMAs the staging writes are spread between
+      constexpr int WG = 0;                           // group whose MFMAs the staging writes are spread between
       constexpr int NW = PA + PB;                     // staging writes per thread per K-step
       constexpr int NMM = MT * NT;                    // MFMA tiles per group
       // The loop body is branch-free: the last K-step also runs its barrier, its "next" fragment reads, its staging writes
@@ -250,7 +199,7 @@ struct TileNT {
         for (int g = 0; g < KG; ++g) {
           const int cur = g & 1, nxt = cur ^ 1;
           if (g + 1 < KG) {
-            if (!SMN_PROBE_NO_FRAG) frag_load(stage, g + 1, lane, wr, wc, fa[nxt], fb[nxt]);
+            frag_load(stage, g + 1, lane, wr, wc, fa[nxt], fb[nxt]);
           } else {
             // Every read of THIS stage must be issued before the barrier: a faster wave overwrites it one group into the
             // next K-step.  The last group's fragments were read a group ago; the empty asm consumes them here so that no
@@ -259,12 +208,9 @@ struct TileNT {
             for (int m = 0; m < MT; ++m) asm volatile("" : "+v"(fa[cur][m]));
 #pragma unroll
             for (int n = 0; n < NT; ++n) asm volatile("" : "+v"(fb[cur][n]));
-            if (!SMN_PROBE_NO_BARRIER) __syncthreads();   // in front of the last group's MFMAs (see above)
-            if (!SMN_PROBE_NO_FRAG) frag_load(nstage, 0, lane, wr, wc, fa[nxt], fb[nxt]);
-#if !SMN_GLOAD_EARLY
-            gload(kt + 2 < last ? kt + 2 : last);    // clamped, not branched around: with a branch here the compiler sank
-#endif
-          }                                            // the previous group's fragment reads below the barrier (a race)
+            __syncthreads();   // in front of the last group's MFMAs (see above)
+            frag_load(nstage, 0, lane, wr, wc, fa[nxt], fb[nxt]);
+          }
           // sched_barrier(0): the compiler's scheduler otherwise sinks the reads back down in front of their first use
           // and gathers the staging writes behind the last MFMA -- the very bubbles this loop is written to remove
           __builtin_amdgcn_sched_barrier(0);
@@ -275,20 +221,19 @@ struct TileNT {
               // the NW staging writes of the next stage, spread over the NMM tile products of this group
 #pragma unroll
               for (int w = 0; w < NW; ++w) {
-                if (!SMN_PROBE_NO_SWRITE && w >= (j * NW) / NMM && w < ((j + 1) * NW) / NMM) {
+                if (w >= (j * NW) / NMM && w < ((j + 1) * NW) / NMM) {
                   if (w < PA) *reinterpret_cast<vec_t*>(nstage + wpos + 32 * w * ROWB) = ra[w < PA ? w : 0];
                   else *reinterpret_cast<vec_t*>(nstage + A_BYTES + wpos + 32 * (w - PA) * ROWB) = rb[w >= PA ? w - PA : 0];
                 }
               }
               __builtin_amdgcn_sched_barrier(0);
-#if SMN_GLOAD_EARLY
               // the staging registers are free as soon as their writes have issued: the loads of the step after the next
-              // go out here, a whole K-step (not half of one) ahead of the writes that wait for them
-              if (j == NMM - 1 && !SMN_PROBE_NO_GLOAD) {
+              // go out here, a whole K-step (not half of one) ahead of the writes that wait for them (clamped, not
+              // branched around: with a branch the compiler sank the previous group's fragment reads below the barrier)
+              if (j == NMM - 1) {
                 gload(kt + 2 < last ? kt + 2 : last);
                 __builtin_amdgcn_sched_barrier(0);
               }
-#endif
             }
           }
           __builtin_amdgcn_sched_barrier(0);

@@ -247,6 +247,8 @@ extern "C" int smn_shard_exchange_part(smn_ctx* ctx, int dtype, const void* mine
   SMN_ENTER(ctx);
   if (!ctx->shard_a || ctx->shard_n != n || ctx->shard_dtype != dtype)
     return smn_fail(ctx, SMN_EINVAL, "smn_shard_exchange_part: smn_shard_begin(dtype, n) first");
+  if (ctx->ws[2] != ctx->shard_a)
+    return smn_fail(ctx, SMN_EINVAL, "smn_shard_exchange_part: the workspace moved since smn_shard_begin");
   const int P = ctx->comm ? ctx->nranks : 1;
   if (nranks != P)   // a world > 1 call on a context without a communicator would quietly gather nothing
     return smn_fail(ctx, SMN_ECOMM, "smn_shard_exchange_part: %d ranks asked for, the context's communicator has %d", nranks, P);

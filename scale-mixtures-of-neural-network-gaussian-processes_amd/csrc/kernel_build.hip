@@ -900,12 +900,15 @@ static int shard_rows(smn_ctx* ctx, int dtype, int net, int act, int num_hiddens
   const int64_t kp = k_pad(dtype, d), r1 = round_up(n, kTile), h = block_rows;
   void* xs = nullptr;
   const size_t xbytes = es * (size_t)kp * (size_t)r1 + sizeof(double) * (size_t)r1;
-  if (reuse_operand && ctx->ws_bytes[0] < xbytes)
-    return smn_fail(ctx, SMN_EINVAL, "smn_kernel_mlp_shard_rows: reuse_operand without a prepared operand");
-  SMN_TRY(smn_workspace(ctx, 0, xbytes, &xs));
+  const bool prepared = ctx->op_x == x_d && ctx->op_n == n && ctx->op_d == d && ctx->op_ldx == ldx && ctx->op_dtype == dtype &&
+                        ctx->ws_bytes[0] >= xbytes;
+  if (reuse_operand && !prepared)
+    return smn_fail(ctx, SMN_EINVAL, "smn_kernel_mlp_shard_rows: reuse_operand, but slot 0 does not hold the padded copy of this x");
+  SMN_TRY(smn_workspace(ctx, 0, xbytes, &xs));   // (clears the tag: set again below)
   double* q1 = static_cast<double*>(xs);
   char* x1p = reinterpret_cast<char*>(q1 + r1);
   if (!reuse_operand) SMN_TRY(pad_rows(ctx, dtype, x_d, n, ldx, d, x1p, r1, kp, q1));
+  ctx->op_x = x_d; ctx->op_n = n; ctx->op_d = d; ctx->op_ldx = ldx; ctx->op_dtype = dtype;
   BuildCall c{};
   c.spec = BuildSpec{dtype, net, act, num_hiddens, w_std, b_std, last_w_std};
   c.kp = (int)kp; c.d = d; c.get_mask = get_mask;

@@ -102,9 +102,9 @@ def build_lower_sharded(ctx, dtype_code, itemsize, net, act, num_hiddens, w_std,
     mine_t = C.c_void_p(ntk_stage_ptr.value + off) if ntk_stage_ptr is not None else None
     ctx.call("smn_kernel_mlp_shard", dtype_code, net, act, num_hiddens, w_std, b_std, last_w_std,
              x_ptr, n, ldx, d, world, rank, h, 1 | (2 if mine_t is not None else 0), mine, mine_t)
-    ctx.call("smn_allgather", dtype_code, mine, stage_ptr, chunk)           # in place
+    ctx.call("smn_allgather", world, dtype_code, mine, stage_ptr, chunk)    # in place
     if mine_t is not None:
-        ctx.call("smn_allgather", dtype_code, mine_t, ntk_stage_ptr, chunk)
+        ctx.call("smn_allgather", world, dtype_code, mine_t, ntk_stage_ptr, chunk)
     if k_ptr is not None:
         ctx.call("smn_unpack_lower_blocks", dtype_code, stage_ptr, n, world, h, k_ptr, ldk)
     if mine_t is not None and ntk_ptr is not None:

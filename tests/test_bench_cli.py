@@ -75,10 +75,18 @@ def test_committed_traffic_file_is_the_one_bench_reads():
 
     import bench
     a = argparse.Namespace(config="c4", n=16384, d=3072, layers=4, act="relu", dtype="f32")
-    assert bench.pmc_traffic(a, False) > 0
-    assert bench.pmc_traffic(a, True) is None
+    for k in bench.SCHEDULE_KNOBS:
+        os.environ.pop(k, None)
+    v, src = bench.pmc_traffic(a, False)
+    assert v > 0 and src.startswith("profiles/")
+    assert bench.pmc_traffic(a, True)[0] is None
+    os.environ["SMN_XCD_MAP"] = "0"                  # an A/B run must not carry the default schedule's counters
+    try:
+        assert bench.pmc_traffic(a, False)[0] is None
+    finally:
+        del os.environ["SMN_XCD_MAP"]
     a.n = 8192
-    assert bench.pmc_traffic(a, False) is None
+    assert bench.pmc_traffic(a, False)[0] is None
 
 
 def test_launcher_ends_the_other_ranks_when_one_fails(tmp_path):

@@ -303,15 +303,19 @@ def test_rccl_single_rank_communicator_allgather(L):
         c.call("smn_comm_init", 1, 0, uid)                                   # already initialised
     src = np.arange(4096, dtype=np.float32)
     a = c.to_device(src); b = c.to_device(np.zeros_like(src))
-    c.call("smn_allgather", L.F32, a.ptr, b.ptr, src.size)                   # out of place
+    c.call("smn_allgather", 1, L.F32, a.ptr, b.ptr, src.size)                # out of place
     assert (b.numpy() == src).all()
-    c.call("smn_allgather", L.F32, a.ptr, a.ptr, src.size)                   # in place (the bench's form)
+    c.call("smn_allgather", 1, L.F32, a.ptr, a.ptr, src.size)                # in place (the bench's form)
     assert (a.numpy() == src).all()
     a64 = c.to_device(src.astype(np.float64)); b64 = c.to_device(np.zeros(src.size))
-    c.call("smn_allgather", L.F64, a64.ptr, b64.ptr, src.size)
+    c.call("smn_allgather", 1, L.F64, a64.ptr, b64.ptr, src.size)
+    with pytest.raises(L.SmnError):
+        c.call("smn_allgather", 2, L.F32, a.ptr, b.ptr, src.size)            # a world the communicator does not have
     assert (b64.numpy() == src).all()
     c.call("smn_comm_destroy")
-    c.call("smn_allgather", L.F32, a.ptr, b.ptr, src.size)                   # no communicator: plain copy
+    c.call("smn_allgather", 1, L.F32, a.ptr, b.ptr, src.size)                # no communicator, a world of one: plain copy
+    with pytest.raises(L.SmnError):
+        c.call("smn_allgather", 2, L.F32, a.ptr, b.ptr, src.size)            # world > 1 without a communicator: refused, not copied
     assert (b.numpy() == src).all()
 
 
@@ -333,7 +337,7 @@ def test_rccl_communicator_in_a_process_that_also_holds_torch(torch_first):
         "c.call('smn_comm_init', 1, 0, uid)",
         "src = np.arange(4096, dtype=np.float32)",
         "a = c.to_device(src); b = c.to_device(np.zeros_like(src))",
-        "c.call('smn_allgather', L.F32, a.ptr, b.ptr, src.size)",
+        "c.call('smn_allgather', 1, L.F32, a.ptr, b.ptr, src.size)",
         "assert (b.numpy() == src).all()",
         "c.call('smn_comm_destroy')",
         "print('ok')"])
@@ -579,19 +583,12 @@ def test_cholesky_more_workgroups_than_cus_and_lookahead(L, ctx, dtype, n, m):
     {"SMN_SUPER": "2048"},
     {"SMN_SUPER": "512", "SMN_CHAIN_CUS": "0"},
     {"SMN_PERSISTENT": "0"},
-    {"SMN_PERSIST_MAXK": "1024"},
     {"SMN_XCD_MAP": "0"},                                      # linear tile order instead of the XCD patch order
-    {"SMN_HALF_TILES": "0"},                                   # no 64-row tiles for the small launches
-    {"SMN_HALF_TILES": "100000"},                              # 64-row tiles everywhere
-    {"SMN_QUARTER_TILES": "0"},                                # no 64x64 tiles for the smallest launches
-    {"SMN_QUARTER_TILES": "100000"},                           # 64x64 tiles everywhere
-    {"SMN_PANEL_SMALL": "0"},                                  # 128-row panel workgroups throughout
     {"SMN_SUPER_WIDE_ROWS": "4096"},                           # 2048-column super-panels while 4096 rows are left, 1024 below
     {"SMN_SUPER_WIDE_ROWS": "0", "SMN_SUPER_WIDE": "3072"},    # 3072-column super-panels throughout
     {"SMN_F0_FIRST_TILES": "0"},                               # F1 always beside F0
     {"SMN_F0_FIRST_TILES": "100000"},                          # F1 always behind F0
-    {"SMN_PANEL_HELPERS": "0"},                                # block updates inside the row waves (panel_kernel)
-    {"SMN_PANEL_HELPERS": "0", "SMN_PANEL_SMALL": "0"},
+    {"SMN_PANEL_LEAF": "0"},                                   # the in-LDS micro-panel kernel (panel_kernel) instead of the register leaf
 ])
 def test_cholesky_schedule_variants_agree(L, env):
     """Every schedule the environment switches select factors the same matrix to the same result (the default
@@ -627,34 +624,37 @@ def test_cholesky_schedule_variants_agree(L, env):
 
 
 @pytest.mark.parametrize("dtype,n,m", [(np.float32, 2048, 128), (np.float32, 4352, 0), (np.float64, 1152, 128)])
-def test_panel_helper_waves_give_the_same_bits(L, dtype, n, m):
-    """panelh_kernel moves the panel's MFMA block updates onto a second set of waves that runs one 16-column block ahead;
-    every accumulator still sees the same K order, so the factor must equal panel_kernel's bit for bit (a hand-off between
-    the helper waves and the row threads that came too early or too late would show here).  Sizes on both sides of the
-    64-row / 128-row switch (SMN_PANEL_SMALL = 4096 rows)."""
+def test_panel_register_leaf_agrees_with_the_lds_micro_panel_kernel(L, dtype, n, m):
+    """panelr_kernel (register-resident 16x16 leaf on DPP broadcasts, block updates behind each leaf on all waves, image
+    streamed in beside the first leaves) against panel_kernel (8-column micro-panels in LDS): two different summation
+    orders of the same factorisation, so agreement to accumulation accuracy -- and twice the leaf kernel bit for bit (a
+    hand-off between the helper waves and the row threads that came too early or too late would show as a run-to-run
+    difference).  Sizes on both sides of the 64-row / 128-row workgroup switch (4096 rows)."""
     import os
     rng = np.random.default_rng(21)
     g = rng.standard_normal((n + m, 64)).astype(dtype)
     a = (g @ g.T / 64 + np.diag(rng.uniform(1.0, 2.0, n + m))).astype(dtype)
     out = []
-    for helpers in ("0", "1"):
-        old = os.environ.get("SMN_PANEL_HELPERS")
-        os.environ["SMN_PANEL_HELPERS"] = helpers
+    for leaf in ("0", "1", "1"):
+        old = os.environ.get("SMN_PANEL_LEAF")
+        os.environ["SMN_PANEL_LEAF"] = leaf
         try:
             c = L.Context(0)
         finally:
             if old is None:
-                del os.environ["SMN_PANEL_HELPERS"]
+                del os.environ["SMN_PANEL_LEAF"]
             else:
-                os.environ["SMN_PANEL_HELPERS"] = old
+                os.environ["SMN_PANEL_LEAF"] = old
         ad = c.to_device(a)
         info, logdet = C.c_int(), C.c_double()
         c.call("smn_cholesky", L.dtype_code(dtype), ad.ptr, n + m, n, n + m, 0, 0.0, 0.0, C.byref(info), C.byref(logdet))
         assert info.value == 0
         out.append((logdet.value, ad.numpy()))
     il = np.tril_indices(n + m)
-    assert out[0][0] == out[1][0]
-    assert np.array_equal(out[0][1][il], out[1][1][il])
+    tol = 1e-5 if dtype == np.float32 else 1e-12
+    assert abs(out[0][0] - out[1][0]) < tol * abs(out[0][0])
+    assert relerr_norm(out[1][1][il], out[0][1][il]) < tol
+    assert out[1][0] == out[2][0] and np.array_equal(out[1][1][il], out[2][1][il])
 
 
 @pytest.mark.parametrize("dtype,n,m", [(np.float32, 9216, 128), (np.float64, 8192, 0)])
