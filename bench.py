@@ -62,6 +62,7 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-recursion-probe", action="store_true")
     p.add_argument("--no-exclusive-probe", action="store_true", help="skip the look-ahead-off pass that fills frac_exclusive")
+    p.add_argument("--with-ntk", action="store_true", help="sharded path: build NNGP + NTK jointly and pipeline both (default for --config c5)")
     p.add_argument("--no-other-workloads", action="store_true",
                    help="skip C2 / C5 / C3 / fp64 / predictive-path measurements appended to the default line")
     p.add_argument("--sharded-path", action="store_true",
@@ -534,10 +535,17 @@ def main():
         parts = args.parts or sharding.default_parts(n, world)
         backend = sharding.DeviceBackend(ctx)
         spec = (L.NET_MLP, act, nl, 1.0, 1e-8, 1.0)
+        # BASELINE config 5 ("erf NNGP + NTK ... shard + single-GPU Cholesky on assembled kernel"): the build launches are the
+        # joint NNGP + NTK ones and the NTK's pieces ride the same pipeline into a full matrix of the caller's
+        ntk = None
+        if args.config == "c5" or args.with_ntk:
+            ntk_arrays = (ctx.empty((chunk,), np_dtype), ctx.empty((world * chunk,), np_dtype), ctx.empty((n, n), np_dtype))
+            res["ntk_arrays"] = ntk_arrays                  # owners stay alive for the run
+            ntk = (ntk_arrays[0].ptr, ntk_arrays[1].ptr, ntk_arrays[2].ptr, n)
 
         def step():
             v = sharding.lml_sharded_pipelined(backend, code, spec, x.ptr, n, d, d, y.ptr, rank, world, mine.ptr, stage.ptr,
-                                               eps, 0.0, 1.0, parts=parts)
+                                               eps, 0.0, 1.0, parts=parts, ntk=ntk)
             res["v"] = (v[0], v[2], v[3])
 
     for _ in range(args.warmup):

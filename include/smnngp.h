@@ -278,6 +278,14 @@ int smn_shard_exchange_part(smn_ctx* ctx, int dtype, const void* mine_d, void* s
                             int64_t block_rows, int parts, int part);
 int smn_lml_from_shards(smn_ctx* ctx, int dtype, int64_t n, const void* y_d, double eps_abs, double df, double scale,
                         double* logpdf_h, double* quad_h, double* logdet_h, int* info_h);
+/* smn_shard_exchange_part with the scatter target named by the caller: k_d [n,n] ld=ldk (lower triangle by 128-column
+ * tiles) instead of the factorisation workspace -- the NTK of a joint NNGP + NTK shard (get_mask = 3 in
+ * smn_kernel_mlp_shard_rows; BASELINE config 5, the reference's only use: sample.ipynb cells 194-195).  Same communication
+ * stream, same ordering.  smn_shard_wait makes the context's main stream wait for every piece issued so far
+ * (smn_lml_from_shards does so by itself). */
+int smn_shard_exchange_part_to(smn_ctx* ctx, int dtype, const void* mine_d, void* stage_d, int64_t n, int nranks,
+                               int64_t block_rows, int parts, int part, void* k_d, int64_t ldk);
+int smn_shard_wait(smn_ctx* ctx);
 
 #ifdef __cplusplus
 }

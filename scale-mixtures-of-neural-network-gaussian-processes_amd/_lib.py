@@ -89,6 +89,8 @@ PROTOTYPES = {
     "smn_kernel_mlp_shard_rows": [_vp, _i, _i, _i, _i, _d, _d, _d, _vp, _i64, _i64, _i64, _i, _i, _i64, _i64, _i64, _i64, _i64,
                                   _i, _i, _vp, _vp],
     "smn_allgather_part": [_vp, _i, _vp, _vp, _i64, _i, _i],
+    "smn_shard_exchange_part_to": [_vp, _i, _vp, _vp, _i64, _i, _i64, _i, _i, _vp, _i64],
+    "smn_shard_wait": [_vp],
     "smn_unpack_lower_parts": [_vp, _i, _vp, _i64, _i, _i64, _i, _i, _i, _vp, _i64],
     "smn_shard_begin": [_vp, _i, _i64],
     "smn_shard_exchange_part": [_vp, _i, _vp, _vp, _i64, _i, _i64, _i, _i],

@@ -268,6 +268,44 @@ extern "C" int smn_shard_exchange_part(smn_ctx* ctx, int dtype, const void* mine
   return SMN_OK;
 }
 
+// The same exchange of one piece, scattered into a matrix of the caller's (the NTK of a joint NNGP + NTK shard: BASELINE
+// config 5) instead of the factorisation workspace.  Same stream, same ordering: behind everything issued so far on the main
+// stream; smn_lml_from_shards (or smn_shard_wait) makes the main stream wait for every piece issued before it.
+extern "C" int smn_shard_exchange_part_to(smn_ctx* ctx, int dtype, const void* mine_d, void* stage_d, int64_t n, int nranks,
+                                          int64_t block_rows, int parts, int part, void* k_d, int64_t ldk) {
+  if (!ctx || !mine_d || !stage_d || !k_d) return SMN_EINVAL;
+  SMN_ENTER(ctx);
+  if (dtype != SMN_F32 && dtype != SMN_F64) return smn_fail(ctx, SMN_EINVAL, "bad dtype");
+  if (n <= 0 || ldk < n) return smn_fail(ctx, SMN_EINVAL, "smn_shard_exchange_part_to: bad sizes");
+  const int P = ctx->comm ? ctx->nranks : 1;
+  if (nranks != P)
+    return smn_fail(ctx, SMN_ECOMM, "smn_shard_exchange_part_to: %d ranks asked for, the context's communicator has %d", nranks, P);
+  const int64_t chunk = block_rows * block_rows * (2 * (int64_t)nranks + 1);
+  hipStream_t sc = ctx->stream_comm;
+  SMN_HIP(ctx, hipEventRecord(ctx->ev_c0, ctx->stream));
+  SMN_HIP(ctx, hipStreamWaitEvent(sc, ctx->ev_c0, 0));
+  {
+    ProfScope ps(ctx, PROF_COMM, sc);
+    SMN_TRY(allgather_part_on(ctx, sc, dtype, mine_d, stage_d, chunk, parts, part));
+  }
+  {
+    ProfScope ps(ctx, PROF_MISC, sc);
+    SMN_TRY(unpack_parts_on(ctx, sc, dtype, stage_d, n, nranks, block_rows, parts, part, part + 1, k_d, ldk));
+  }
+  SMN_HIP(ctx, hipEventRecord(ctx->ev_c1, sc));
+  return SMN_OK;
+}
+
+// The main stream waits for every piece issued so far (for callers of smn_shard_exchange_part_to that do not finish with
+// smn_lml_from_shards).
+extern "C" int smn_shard_wait(smn_ctx* ctx) {
+  if (!ctx) return SMN_EINVAL;
+  SMN_ENTER(ctx);
+  ProfScope ps(ctx, PROF_EXPOSED, ctx->stream);
+  SMN_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_c1, 0));
+  return SMN_OK;
+}
+
 extern "C" int smn_lml_from_shards(smn_ctx* ctx, int dtype, int64_t n, const void* y_d, double eps_abs, double df,
                                    double scale, double* logpdf_h, double* quad_h, double* logdet_h, int* info_h) {
   if (!ctx || !y_d) return SMN_EINVAL;

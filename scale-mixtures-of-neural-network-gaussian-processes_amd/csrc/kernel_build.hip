@@ -545,11 +545,25 @@ template <typename T, int NET, int ACT, bool NTK>
 int launch_build_t(smn_ctx* ctx, const BuildArgs<T>& a, int64_t ntiles, size_t lds) {
   auto kern = build_kernel<T, NET, ACT, NTK>;
   SMN_TRY(smn_allow_lds(ctx, reinterpret_cast<const void*>(kern), lds));
+  // A sharded build beside a live exchange (communicator of more than one rank, or SMN_COMM_CUS_FORCE for rehearsals) goes to
+  // the stream whose CU mask leaves comm_cus CUs alone: RCCL's all-gather is a kernel too, and behind a build that fills every
+  // CU with two workgroups it would only run as the build drains -- the exposed exchange would be the whole exchange, not the
+  // last piece.  Same order as on the main stream (an event either side).
+  const bool masked = a.shard && ctx->stream_build && ctx->comm_cus > 0 && ((ctx->comm && ctx->nranks > 1) || ctx->comm_cus_force);
+  hipStream_t st = masked ? ctx->stream_build : ctx->stream;
+  if (masked) {
+    SMN_HIP(ctx, hipEventRecord(ctx->ev_b0, ctx->stream));
+    SMN_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_b0, 0));
+  }
   {
-    ProfScope ps(ctx, PROF_BUILD, ctx->stream);
-    hipLaunchKernelGGL(kern, dim3((unsigned)ntiles), dim3(256), lds, ctx->stream, a);
+    ProfScope ps(ctx, PROF_BUILD, st);
+    hipLaunchKernelGGL(kern, dim3((unsigned)ntiles), dim3(256), lds, st, a);
   }
   SMN_CHECK_LAUNCH(ctx);
+  if (masked) {
+    SMN_HIP(ctx, hipEventRecord(ctx->ev_b1, st));
+    SMN_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_b1, 0));
+  }
   return SMN_OK;
 }
 

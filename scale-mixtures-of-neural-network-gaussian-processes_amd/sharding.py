@@ -186,14 +186,18 @@ class DeviceBackend:
     def begin(self, dtype_code, n):
         self.ctx.call("smn_shard_begin", dtype_code, n)
 
-    def build_rows(self, dtype_code, spec, x_ptr, n, ldx, d, world, rank, h, rows, reuse, mine_ptr):
+    def build_rows(self, dtype_code, spec, x_ptr, n, ldx, d, world, rank, h, rows, reuse, mine_ptr, ntk_mine_ptr=None):
         net, act, num_hiddens, w_std, b_std, last_w_std = spec
         self.ctx.call("smn_kernel_mlp_shard_rows", dtype_code, net, act, num_hiddens, w_std, b_std, last_w_std,
-                      x_ptr, n, ldx, d, world, rank, h, rows[0], rows[1], rows[2], rows[3], 1 if reuse else 0, 1,
-                      mine_ptr, None)
+                      x_ptr, n, ldx, d, world, rank, h, rows[0], rows[1], rows[2], rows[3], 1 if reuse else 0,
+                      1 | (2 if ntk_mine_ptr is not None else 0), mine_ptr, ntk_mine_ptr)
 
-    def exchange_part(self, dtype_code, mine_ptr, stage_ptr, n, world, h, parts, part):
+    def exchange_part(self, dtype_code, mine_ptr, stage_ptr, n, world, h, parts, part, ntk=None):
+        """Piece `part` of the NNGP chunks into the factorisation workspace; with ntk = (mine, stage, out, ld) also the
+        same piece of the NTK chunks into the caller's matrix `out`.  Both on the communication stream."""
         self.ctx.call("smn_shard_exchange_part", dtype_code, mine_ptr, stage_ptr, n, world, h, parts, part)
+        if ntk is not None:
+            self.ctx.call("smn_shard_exchange_part_to", dtype_code, ntk[0], ntk[1], n, world, h, parts, part, ntk[2], ntk[3])
 
     def lml(self, dtype_code, n, y_ptr, eps_abs, df, scale):
         import ctypes as C
@@ -204,10 +208,13 @@ class DeviceBackend:
 
 
 def lml_sharded_pipelined(backend, dtype_code, spec, x_ptr, n, ldx, d, y_ptr, rank, world, mine_ptr, stage_ptr,
-                          eps_abs, df=0.0, scale=1.0, parts=None):
+                          eps_abs, df=0.0, scale=1.0, parts=None, ntk=None):
     """One SPR.loss evaluation with the kernel build sharded over `world` ranks and the exchange pipelined behind it
     (`spec` = (net, act, num_hiddens, w_std, b_std, last_w_std); mine: the rank's chunk, paired_chunk_elems elements;
-    stage: world * that).  Returns (logpdf, quad, logdet, info); every rank computes the same values."""
+    stage: world * that).  Returns (logpdf, quad, logdet, info); every rank computes the same values.
+    ntk = (mine, stage, out, ld): the build also produces the NTK (one joint launch per piece: BASELINE config 5's "erf NNGP
+    + NTK"), whose pieces ride the same pipeline and are assembled in the caller's matrix `out` (lower triangle by
+    128-column tiles) by the time the likelihood has been read."""
     if backend.comm_size() != world:
         raise RuntimeError("sharded build over %d ranks, but the communicator has %d (smn_comm_init first)"
                            % (world, backend.comm_size()))
@@ -217,7 +224,13 @@ def lml_sharded_pipelined(backend, dtype_code, spec, x_ptr, n, ldx, d, y_ptr, ra
     padded = False
     for g, rows in enumerate(part_tile_rows(n, world, rank, parts)):
         if rows[1] > rows[0] or rows[3] > rows[2]:
-            backend.build_rows(dtype_code, spec, x_ptr, n, ldx, d, world, rank, h, rows, padded, mine_ptr)
+            if ntk is None:
+                backend.build_rows(dtype_code, spec, x_ptr, n, ldx, d, world, rank, h, rows, padded, mine_ptr)
+            else:
+                backend.build_rows(dtype_code, spec, x_ptr, n, ldx, d, world, rank, h, rows, padded, mine_ptr, ntk[0])
             padded = True
-        backend.exchange_part(dtype_code, mine_ptr, stage_ptr, n, world, h, parts, g)
+        if ntk is None:
+            backend.exchange_part(dtype_code, mine_ptr, stage_ptr, n, world, h, parts, g)
+        else:
+            backend.exchange_part(dtype_code, mine_ptr, stage_ptr, n, world, h, parts, g, ntk)
     return backend.lml(dtype_code, n, y_ptr, eps_abs, df, scale)

@@ -1164,28 +1164,34 @@ def test_pipelined_pieces_assemble_the_same_kernel(L, ctx, n, d, world, parts):
     h, chunk = S.block_rows(n, world), S.paired_chunk_elems(n, world)
     piece = chunk // parts
     stage = ctx.to_device(np.full(world * chunk, np.nan, np.float32))
+    stage_t = ctx.to_device(np.full(world * chunk, np.nan, np.float32))      # the NTK rides the same pieces (config 5)
     be = S.DeviceBackend(ctx)
     for r in range(world):
         mine = ctx.to_device(np.full(chunk, np.nan, np.float32))
+        mine_t = ctx.to_device(np.full(chunk, np.nan, np.float32))
         padded = False
         for g, rows in enumerate(S.part_tile_rows(n, world, r, parts)):
             if rows[1] > rows[0] or rows[3] > rows[2]:
-                be.build_rows(L.F32, spec, x.ptr, n, d, d, world, r, h, rows, padded, mine.ptr)
+                be.build_rows(L.F32, spec, x.ptr, n, d, d, world, r, h, rows, padded, mine.ptr, mine_t.ptr)
                 padded = True
             # what the all-gather of piece g does for rank r
-            ctx.call("smn_memcpy_d2d", C.c_void_p(stage.ptr.value + 4 * (g * world + r) * piece),
-                     C.c_void_p(mine.ptr.value + 4 * g * piece), 4 * piece)
+            for src, dst in ((mine, stage), (mine_t, stage_t)):
+                ctx.call("smn_memcpy_d2d", C.c_void_p(dst.ptr.value + 4 * (g * world + r) * piece),
+                         C.c_void_p(src.ptr.value + 4 * g * piece), 4 * piece)
         ctx.synchronize()
-        del mine
+        del mine, mine_t
     k = ctx.to_device(np.full((n, n), np.nan, np.float32))
+    kt = ctx.to_device(np.full((n, n), np.nan, np.float32))
     ctx.call("smn_unpack_lower_parts", L.F32, stage.ptr, n, world, h, parts, 0, parts, k.ptr, n)
+    ctx.call("smn_unpack_lower_parts", L.F32, stage_t.ptr, n, world, h, parts, 0, parts, kt.ptr, n)
     ref = ctx.empty((n, n), np.float32)
-    ctx.call("smn_kernel_mlp", L.F32, *spec, x.ptr, n, d, None, 0, 0, d, L.GET_NNGP, L.FILL_LOWER, ref.ptr, None, n)
-    got, want = k.numpy(), ref.numpy()
+    ref_t = ctx.empty((n, n), np.float32)
+    ctx.call("smn_kernel_mlp", L.F32, *spec, x.ptr, n, d, None, 0, 0, d, L.GET_NNGP | L.GET_NTK, L.FILL_LOWER, ref.ptr, ref_t.ptr, n)
     rr, cc = np.indices((n, n))
     own = cc < np.minimum(n, (rr // 128 + 1) * 128)          # the lower triangle by 128-column tiles
-    assert np.array_equal(got[own], want[own])
-    assert np.isnan(got[~own]).all()
+    for got, want in ((k.numpy(), ref.numpy()), (kt.numpy(), ref_t.numpy())):
+        assert np.array_equal(got[own], want[own])
+        assert np.isnan(got[~own]).all()
 
 
 def test_pipelined_route_on_a_one_rank_communicator(L, ctx):
@@ -1213,6 +1219,31 @@ def test_pipelined_route_on_a_one_rank_communicator(L, ctx):
         assert abs(got[0] - lp.value) < 1e-6 * abs(lp.value) and abs(got[2] - logdet.value) < 1e-6 * abs(logdet.value)
     with pytest.raises(RuntimeError):
         S.lml_sharded_pipelined(S.DeviceBackend(c2), L.F32, spec, x2.ptr, n, d, d, y2.ptr, 0, 2, mine.ptr, stage.ptr, 1e-2)
+    # BASELINE config 5: NNGP + NTK through the same pipeline (smn_shard_exchange_part_to), with the sharded build on the
+    # CU-masked stream that keeps CUs free for RCCL's kernels (forced here: a one-rank communicator would not ask for it)
+    import os
+    os.environ["SMN_COMM_CUS_FORCE"] = "1"
+    try:
+        c3 = L.Context(ctx.device)
+    finally:
+        del os.environ["SMN_COMM_CUS_FORCE"]
+    assert L._lib.smn_comm_unique_id(uid) == 0
+    c3.call("smn_comm_init", 1, 0, uid)
+    x3 = c3.to_device(x.numpy()); y3 = c3.to_device(y.numpy())
+    mine3 = c3.empty((chunk,), np.float32); stage3 = c3.empty((chunk,), np.float32)
+    mine_t = c3.empty((chunk,), np.float32); stage_t = c3.empty((chunk,), np.float32)
+    tk = c3.to_device(np.full((n, n), np.nan, np.float32))
+    got = S.lml_sharded_pipelined(S.DeviceBackend(c3), L.F32, spec, x3.ptr, n, d, d, y3.ptr, 0, 1, mine3.ptr, stage3.ptr,
+                                  1e-2, parts=4, ntk=(mine_t.ptr, stage_t.ptr, tk.ptr, n))
+    assert got[3] == 0 and abs(got[0] - lp.value) < 1e-6 * abs(lp.value)
+    ref = ctx.empty((n, n), np.float32); ref_t = ctx.empty((n, n), np.float32)
+    ctx.call("smn_kernel_mlp", L.F32, *spec, x.ptr, n, d, None, 0, 0, d, L.GET_NNGP | L.GET_NTK, L.FILL_LOWER, ref.ptr, ref_t.ptr, n)
+    rr, cc = np.indices((n, n))
+    own = cc < np.minimum(n, (rr // 128 + 1) * 128)
+    assert np.array_equal(tk.numpy()[own], ref_t.numpy()[own]) and np.isnan(tk.numpy()[~own]).all()
+    with pytest.raises(L.SmnError):
+        c3.call("smn_shard_exchange_part_to", L.F32, mine_t.ptr, stage_t.ptr, n, 2, S.block_rows(n, 1), 4, 0, tk.ptr, n)
+    c3.call("smn_comm_destroy")
     with pytest.raises(RuntimeError):       # the unpipelined route checks the communicator too
         S.build_lower_sharded(c2, L.F32, 4, *spec, x2.ptr, n, d, d, 0, 2, stage.ptr, None, 0)
     c2.call("smn_comm_destroy")

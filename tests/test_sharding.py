@@ -227,7 +227,7 @@ class _CpuBackend:
         self.k = np.full((n, n), np.nan)
         self.calls.append("begin")
 
-    def build_rows(self, dtype_code, spec, x_ptr, n, ldx, d, world, rank, h, rows, reuse, mine):
+    def build_rows(self, dtype_code, spec, x_ptr, n, ldx, d, world, rank, h, rows, reuse, mine, ntk_mine=None):
         from oracle import nngp_oracle as O
         from smnngp import sharding as S
         _net, act, nh, w_std, b_std, lw = spec
@@ -240,12 +240,26 @@ class _CpuBackend:
             kr = O.mlp_kernel(self.x[rb:re], self.x[:re], nh, "relu" if act == 0 else "erf", w_std, b_std, lw)
             kr[np.arange(re - rb), np.arange(rb, re)] = O.diag_recursion((self.x[rb:re] ** 2).sum(1) / d, nh,
                                                                          "relu" if act == 0 else "erf", w_std, b_std, lw)
+            if ntk_mine is not None:
+                both = O.mlp_kernel(self.x[rb:re], self.x[:re], nh, "relu" if act == 0 else "erf", w_std, b_std, lw, get=("nngp", "ntk"))
+                kt = both[1]
+                if re - rb:                                   # exact diagonal, as the device kernel writes it
+                    full = O.mlp_kernel(self.x[rb:re], None, nh, "relu" if act == 0 else "erf", w_std, b_std, lw, get=("nngp", "ntk"))[1]
+                    kt[np.arange(re - rb), np.arange(rb, re)] = np.diag(full)
             for i in range(re - rb):
                 o = base + (rb - blk * h + i) * ld
                 mine[o: o + re] = kr[i]
+                if ntk_mine is not None:
+                    ntk_mine[o: o + re] = kt[i]
         self.calls.append(("build", rows, bool(reuse)))
 
-    def exchange_part(self, dtype_code, mine, stage, n, world, h, parts, part):
+    def exchange_part(self, dtype_code, mine, stage, n, world, h, parts, part, ntk=None):
+        if ntk is not None:                                   # the same piece of the NTK chunks into the caller's matrix
+            self._exchange(ntk[0], ntk[1], n, world, h, parts, part, ntk[2])
+        self._exchange(mine, stage, n, world, h, parts, part, self.k)
+        self.calls.append(("exchange", part))
+
+    def _exchange(self, mine, stage, n, world, h, parts, part, out):
         piece = mine.size // parts
         recv = self.torch.from_numpy(stage[part * world * piece: (part + 1) * world * piece])
         self.dist.all_gather_into_tensor(recv, self.torch.from_numpy(mine[part * piece: (part + 1) * piece].copy()))
@@ -259,8 +273,7 @@ class _CpuBackend:
                     b, ld, ee = 2 * world - 1 - r, (2 * world - r) * h, e - low
                 row, col = b * h + ee // ld, ee % ld
                 if row < n and col < min(n, (row // 128 + 1) * 128):
-                    self.k[row, col] = stage[(part * world + r) * piece + v]
-        self.calls.append(("exchange", part))
+                    out[row, col] = stage[(part * world + r) * piece + v]
 
     def lml(self, dtype_code, n, y_ptr, eps_abs, df, scale):
         from oracle import nngp_oracle as O
@@ -270,7 +283,7 @@ class _CpuBackend:
         return lp, 0.0, 0.0, 0
 
 
-def _pipelined_worker(rank, world, port, n, d, parts, q):
+def _pipelined_worker(rank, world, port, n, d, parts, q, with_ntk=False):
     import torch
     import torch.distributed as dist
     sys.path.insert(0, ROOT)
@@ -284,7 +297,11 @@ def _pipelined_worker(rank, world, port, n, d, parts, q):
         mine = np.full(chunk, np.nan); stage = np.full(world * chunk, np.nan)
         be = _CpuBackend(dist, torch, x, y, world, rank)
         spec = (0, 0, 2, 1.2, 0.3, 1.0)
-        lp, _, _, info = S.lml_sharded_pipelined(be, 1, spec, None, n, d, d, None, rank, world, mine, stage, 1e-3, parts=parts)
+        ntk = None
+        if with_ntk:
+            tk = np.full((n, n), np.nan)
+            ntk = (np.full(chunk, np.nan), np.full(world * chunk, np.nan), tk, n)
+        lp, _, _, info = S.lml_sharded_pipelined(be, 1, spec, None, n, d, d, None, rank, world, mine, stage, 1e-3, parts=parts, ntk=ntk)
         # the driver's order: begin, then for every piece its build (if it adds rows) BEFORE its exchange, pieces in order
         ex = [c[1] for c in be.calls if c[0] == "exchange"]
         assert be.calls[0] == "begin" and ex == list(range(parts))
@@ -296,13 +313,13 @@ def _pipelined_worker(rank, world, port, n, d, parts, q):
         except RuntimeError:
             raised = True
         if rank == 0:
-            q.put((be.ks, lp, raised))
+            q.put((be.ks, lp, raised, None if ntk is None else np.tril(ntk[2])))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n,parts", [(300, 4), (513, 8), (200, 1)])
-def test_world_size_2_gloo_pipelined_driver_with_cpu_backend(n, parts):
+@pytest.mark.parametrize("n,parts,with_ntk", [(300, 4, False), (513, 8, False), (200, 1, False), (300, 4, True)])
+def test_world_size_2_gloo_pipelined_driver_with_cpu_backend(n, parts, with_ntk):
     """Two gloo processes run sharding.lml_sharded_pipelined itself -- the function bench.py --gpus N runs on the GPUs --
     with the device steps replaced by a CPU backend: piece-wise build, piece-wise all-gather, scatter, head."""
     pytest.importorskip("torch")
@@ -312,10 +329,10 @@ def test_world_size_2_gloo_pipelined_driver_with_cpu_backend(n, parts):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     d = 5
-    procs = [ctx.Process(target=_pipelined_worker, args=(r, 2, port, n, d, parts, q)) for r in range(2)]
+    procs = [ctx.Process(target=_pipelined_worker, args=(r, 2, port, n, d, parts, q, with_ntk)) for r in range(2)]
     for p in procs:
         p.start()
-    k, lml, raised = q.get(timeout=180)
+    k, lml, raised, tk = q.get(timeout=180)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -326,3 +343,9 @@ def test_world_size_2_gloo_pipelined_driver_with_cpu_backend(n, parts):
     ref_lml = O.mvn_logpdf(y, ref + 1e-3 * np.eye(n))
     assert abs(lml - ref_lml) < 1e-9 * abs(ref_lml)
     assert raised            # a world the communicator does not have is refused
+    if with_ntk:             # BASELINE config 5: the NTK rides the same pipeline, piece by piece
+        ref_t = O.mlp_kernel(x, None, 2, "relu", 1.2, 0.3, 1.0, get=("nngp", "ntk"))[1]
+        rr, cc = np.indices((n, n))
+        own = cc < np.minimum(n, (rr // 128 + 1) * 128)
+        low = own & (cc <= rr)
+        assert np.allclose(tk[low], ref_t[low], rtol=1e-12, atol=1e-14)
