@@ -265,6 +265,7 @@ extern "C" int smn_ctx_create(int device_id, smn_ctx** out) {
   if (const char* e = getenv("SMN_REC_SYM")) c->rec_sym = e[0] != '0';
   if (const char* e = getenv("SMN_CNN_TILED")) c->cnn_tiled = atoi(e);
   if (const char* e = getenv("SMN_CNN_FAST32")) c->cnn_fast32 = atoi(e);
+  if (const char* e = getenv("SMN_CNN_PATCH44")) c->cnn_patch44 = e[0] != '0';
   if (const char* e = getenv("SMN_SUPER")) c->super_panel = atol(e);
   if (const char* e = getenv("SMN_SUPER_WIDE")) c->super_panel_wide = atol(e);
   if (const char* e = getenv("SMN_SUPER_WIDE_ROWS")) c->super_wide_rows = atol(e);

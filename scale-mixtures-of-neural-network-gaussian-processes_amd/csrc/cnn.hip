@@ -11,6 +11,8 @@
 // pre-activation variance maps q~_l[n,h,w] (the same stencil recursion on the diagonal) are computed
 // once per image by conv_q_kernel and streamed from L2.  VALU-bound by construction (a 9-tap sum and
 // an asin per pixel, pair and layer); no MFMA: there is no GEMM here to find.
+#include <type_traits>
+
 #include "internal.hpp"
 #include "nngp_math.hpp"
 
@@ -44,9 +46,21 @@ struct ConvProg {
 // bound by streaming these tables out of L2, not by its arithmetic:
 //   ReLU: r = 1/sqrt(q~) (0 where q~ <= 0); the second factor s_i s_j = sqrt(q_i q_j)/(2 pi) = 1/(2 pi r_i r_j)
 //   erf:  r = 1/sqrt(1 + 2 q~)
+// patch44 != 0 (32x32 images, conv_pair44_kernel): R is written in the order that kernel's lanes read it -- for layer l the
+// vectors [j = 4-pixel patch row r x vector v][lane = patch (py, px)][16 bytes], so one load instruction of a wave is 1 KB of
+// consecutive bytes -- and xperm receives the image in the same order ([vector of a patch row][lane][16 bytes], a patch
+// row being 4 pixels x C channels).  Gathered patch rows straight from the [pixel][channel] image cost the pair kernel 44 %
+// of its time (6x the cache-line look-ups: profiles/r03_cnn_phase_timing.txt).
+template <typename T>
+__device__ __forceinline__ int64_t patch44_index(int px, int vec_elems) {   // pixel -> element index inside one layer's table
+  const int row = px >> 5, col = px & 31;
+  const int lane = (row >> 2) * 8 + (col >> 2), r = row & 3, c = col & 3;
+  const int rv = 4 / vec_elems;                                              // vectors per patch row
+  return ((int64_t)(r * rv + c / vec_elems) * 64 + lane) * vec_elems + c % vec_elems;
+}
 template <typename T>
 __global__ void __launch_bounds__(256) conv_q_kernel(const T* __restrict__ x, int64_t n, ConvProg p,
-                                                     T* __restrict__ R, T* __restrict__ diag) {
+                                                     T* __restrict__ R, T* __restrict__ diag, int patch44, T* __restrict__ xperm) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int H = p.H, W = p.W, HW = H * W, PW = W + 2, PSZ = (H + 2) * PW;
   double* m0 = reinterpret_cast<double*>(smem);   // padded map, double for the diagonal
@@ -69,7 +83,7 @@ __global__ void __launch_bounds__(256) conv_q_kernel(const T* __restrict__ x, in
       const double* c = cur + h * PW + w;   // top-left of the 3x3 window in the padded map
       const double bs = c[0] + c[1] + c[2] + c[PW] + c[PW + 1] + c[PW + 2] + c[2 * PW] + c[2 * PW + 1] + c[2 * PW + 2];
       const double qt = p.w2 * bs / 9.0 + p.b2;
-      const int64_t ti = (img * p.layers + l) * HW + px;
+      const int64_t ti = (img * p.layers + l) * HW + (patch44 ? patch44_index<T>(px, 16 / (int)sizeof(T)) : (int64_t)px);
       if (p.act == 0) R[ti] = qt > 0.0 ? (T)(1.0 / sqrt(qt)) : T(0);
       else R[ti] = (T)(1.0 / sqrt(1.0 + 2.0 * qt));
       const double qa = p.act == 0 ? 0.5 * qt : (2.0 / nngp::kPi) * asin(2.0 * qt / (1.0 + 2.0 * qt));
@@ -77,6 +91,17 @@ __global__ void __launch_bounds__(256) conv_q_kernel(const T* __restrict__ x, in
     }
     __syncthreads();
     double* t = cur; cur = nxt; nxt = t;
+  }
+  if (patch44 && xperm) {
+    // element e' = c4 * C + ch of patch row r of lane `lane` lives in vector (r * XV + e' / VEC), slot e' % VEC
+    constexpr int VEC = 16 / (int)sizeof(T);
+    const int C = p.C, XV = 4 * C / VEC;
+    for (int i = threadIdx.x; i < HW * C; i += blockDim.x) {
+      const int px = i / C, ch = i % C;
+      const int row = px >> 5, col = px & 31;
+      const int lane = (row >> 2) * 8 + (col >> 2), r = row & 3, e = (col & 3) * C + ch;
+      xperm[img * HW * C + ((int64_t)(r * XV + e / VEC) * 64 + lane) * VEC + e % VEC] = x[img * HW * C + i];
+    }
   }
   // mean over pixels (block tree reduction in the free map)
   double s = 0.0;
@@ -388,6 +413,168 @@ __global__ void __launch_bounds__(256, SMN_CNN32_OCC) conv_pair32_kernel(PairArg
   }
 }
 
+// conv_pair44_kernel — 32x32 images, one wave per image pair, a 4x4 PATCH of pixels per lane (round 3).
+// conv_pair32_kernel keeps one pixel row pair per half-wave and moves every pixel's value to its neighbours (two DPP moves
+// and a v_permlane32_swap per pixel and layer, 18 of its 65 vector instructions per pixel and layer, f64:
+// profiles/r03_cnn_instruction_budget.txt).  With lane (py, px) = (lane >> 3, lane & 7) holding rows 4 py .. 4 py + 3 x columns
+// 4 px .. 4 px + 3, the separable 3 + 3 box sum runs inside the lane's registers: per layer and lane 48 additions for 16 pixels and
+// 16 halo values from the four neighbouring lanes, fetched by ds_bpermute_b32 (the LDS crossbar: no LDS memory, no vector-ALU
+// instruction).  Border patches multiply their missing halo by a 0 / 1 factor folded into the addition (an fma).  The loads
+// are whole 16-byte vectors as well: a patch row is 4 consecutive pixels, so its C channels and its factor-table entries
+// are contiguous.  One reciprocal step less for 1 / (r_i r_j) (v_rcp_f64 + one Newton step: 2^-50, against 2 steps).
+typedef float cnn_f32x4 __attribute__((ext_vector_type(4)));
+typedef double cnn_f64x2 __attribute__((ext_vector_type(2)));
+template <typename T>
+__device__ __forceinline__ T lane_fetch(T v, int src_lane_bytes);
+template <>
+__device__ __forceinline__ float lane_fetch<float>(float v, int sb) {
+  return __int_as_float(__builtin_amdgcn_ds_bpermute(sb, __float_as_int(v)));
+}
+template <>
+__device__ __forceinline__ double lane_fetch<double>(double v, int sb) {
+  return __hiloint2double(__builtin_amdgcn_ds_bpermute(sb, __double2hiint(v)), __builtin_amdgcn_ds_bpermute(sb, __double2loint(v)));
+}
+__device__ __forceinline__ float rcp_fast(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ double rcp_fast(double x) {
+  const double r = __builtin_amdgcn_rcp(x);
+  return fma(fma(-x, r, 1.0), r, r);
+}
+
+template <typename T, int ACT, int C>
+__global__ void __launch_bounds__(256, SMN_CNN32_OCC) conv_pair44_kernel(PairArgs<T> a) {
+  constexpr int HW = 1024, VEC = 16 / sizeof(T);
+  constexpr int XV = 4 * C / VEC;          // 16-byte vectors of one patch row of an input image (4 pixels x C channels)
+  constexpr int RV = 4 / VEC;              // ... of one patch row of a factor table (4 pixels); 1 (f32: 4 per vector) or 2
+  static_assert((4 * C) % VEC == 0 && 4 % VEC == 0, "patch rows are whole 16-byte vectors");
+  using vec_t = typename std::conditional<sizeof(T) == 8, cnn_f64x2, cnn_f32x4>::type;
+  const ConvProg& p = a.prog;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int py = lane >> 3, px = lane & 7;
+  const T ml = px > 0 ? T(1) : T(0), mr = px < 7 ? T(1) : T(0), mt = py > 0 ? T(1) : T(0), mb = py < 7 ? T(1) : T(0);
+  const int sl = 4 * (px > 0 ? lane - 1 : lane), sr = 4 * (px < 7 ? lane + 1 : lane);     // ds_bpermute source lanes (x 4 bytes)
+  const int st = 4 * (py > 0 ? lane - 8 : lane), sb = 4 * (py < 7 ? lane + 8 : lane);
+  const T w2_9 = (T)(p.w2 / 9.0), b2 = (T)p.b2;
+  const T inv_c = (T)(1.0 / C);
+  PairWalk<T> walk(a, wave);
+  int64_t n, m;
+#ifdef SMN_CNN_TIMING   // wave 0 of workgroup 0: s_memtime cycles per phase, summed over its pairs
+  long long tc[4] = {0, 0, 0, 0}, tp = __builtin_readcyclecounter();
+  int npair = 0;
+#define CT(i) do { const long long n_ = __builtin_readcyclecounter(); tc[i] += n_ - tp; tp = n_; } while (0)
+#else
+#define CT(i)
+#endif
+  while (walk.next(n, m)) {
+    CT(3);
+    const T* xa = a.x1 + n * HW * C + lane * VEC;    // a.x1 / a.x2: the patch-order copies made by conv_q_kernel
+    const T* xb = a.x2 + m * HW * C + lane * VEC;
+    T val[4][4];
+    {
+      vec_t va[4][XV], vb[4][XV];            // all loads of the pair's inputs in flight at once
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int v = 0; v < XV; ++v) {
+          va[r][v] = *reinterpret_cast<const vec_t*>(xa + (r * XV + v) * 64 * VEC);
+          vb[r][v] = *reinterpret_cast<const vec_t*>(xb + (r * XV + v) * 64 * VEC);
+        }
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          T s = T(0);
+#pragma unroll
+          for (int ch = 0; ch < C; ++ch) {
+            const int e = c * C + ch;
+            s = fma(va[r][e / VEC][e % VEC], vb[r][e / VEC][e % VEC], s);
+          }
+          val[r][c] = s * inv_c;
+        }
+    }
+    asm volatile("" : "+v"(val[0][0]));
+    CT(0);
+    for (int l = 0; l < p.layers; ++l) {
+      const T* r1 = a.R1 + (n * p.layers + l) * HW + lane * VEC;
+      const T* r2 = a.R2 + (m * p.layers + l) * HW + lane * VEC;
+      vec_t t1[4][RV], t2[4][RV];            // factor tables: requested first, used last
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int v = 0; v < RV; ++v) {
+          t1[r][v] = *reinterpret_cast<const vec_t*>(r1 + (r * RV + v) * 64 * VEC);
+          t2[r][v] = *reinterpret_cast<const vec_t*>(r2 + (r * RV + v) * 64 * VEC);
+        }
+      // horizontal 3-sums; the halo columns come from the lanes left and right
+      T hl[4], hr[4], h[4][4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        hl[r] = lane_fetch<T>(val[r][3], sl);
+        hr[r] = lane_fetch<T>(val[r][0], sr);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const T s01 = val[r][0] + val[r][1], s23 = val[r][2] + val[r][3];
+        h[r][1] = s01 + val[r][2];
+        h[r][2] = val[r][1] + s23;
+        h[r][0] = fma(ml, hl[r], s01);
+        h[r][3] = fma(mr, hr[r], s23);
+      }
+      // vertical 3-sums; the halo rows come from the lanes above and below
+      T ht[4], hb[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        ht[c] = lane_fetch<T>(h[3][c], st);
+        hb[c] = lane_fetch<T>(h[0][c], sb);
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const T s01 = h[0][c] + h[1][c], s23 = h[2][c] + h[3][c];
+        const T b1 = s01 + h[2][c], b2_ = h[1][c] + s23;
+        const T b0 = fma(mt, ht[c], s01), b3 = fma(mb, hb[c], s23);
+        T bs[4] = {b0, b1, b2_, b3};
+#ifdef SMN_CNN_TIMING
+        if (c == 0) { asm volatile("" : "+v"(bs[0])); CT(1); }
+#endif
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const T rr = t1[r][c / VEC][c % VEC] * t2[r][c / VEC][c % VEC];
+          const T kt = fma(w2_9, bs[r], b2);
+          if (ACT == 0) {
+            const T ss = rr > T(0) ? T(1.0 / (2.0 * nngp::kPi)) * rcp_fast(rr) : T(0);
+            val[r][c] = nngp::relu_map<T, false>(kt, rr, ss).k;
+          } else {
+            val[r][c] = nngp::erf_map<T, false>(kt, rr, T(0)).k;
+          }
+        }
+      }
+    }
+    asm volatile("" : "+v"(val[0][0]));
+    CT(2);
+#ifdef SMN_CNN_TIMING
+    ++npair;
+#endif
+    T s = T(0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) s += val[r][c];
+#pragma unroll
+    for (int o2 = 32; o2 > 0; o2 >>= 1) s += __shfl_xor(s, o2);
+    if (lane == 0) {
+      T v = (T)p.lw2 * s / (T)HW;
+      if (a.symmetric && n == m) v = a.diag[n];
+      a.out[n * a.ldo + m] = v;
+      if (a.symmetric && a.mirror && n != m) a.out[m * a.ldo + n] = v;
+    }
+  }
+#ifdef SMN_CNN_TIMING
+  if (threadIdx.x == 0 && blockIdx.x == 0 && npair > 0)
+    printf("conv_pair44 wg0 wave0: %d pairs; cycles per pair: K0 (x loads + products) %lld, box sums of %d layers (incl. waiting for the halo) %lld, activation maps %lld, reduce/store/next %lld\n",
+           npair, tc[0] / npair, p.layers, tc[1] / npair, tc[2] / npair, tc[3] / npair);
+#endif
+#undef CT
+}
+
 // Launch one form of the pair kernel.  Tiled pair order once there are >= 64 tiles per XCD: the grid is then exactly the
 // resident set (occupancy API; a multiple of 64 workgroups, so a tile is a whole number of 32-pair rows).
 // cnn_tiled: 0 never, 1 by size, 2 always (tests).
@@ -413,8 +600,13 @@ template <typename T, int ACT>
 int launch_pairs(smn_ctx* ctx, const PairArgs<T>& a, int64_t blocks, size_t lds, int64_t hw) {
   // register-only stencil, no LDS: fp64 by default (+2 ... +11 % with growing N; the fp32 LDS-map kernel is VALU-bound at
   // 72 % busy and 5 % FASTER than its register form: profiles/r01f_cnn_fast32_ab.txt); cnn_fast32 = 2 forces it for both
-  if (a.prog.H == 32 && a.prog.W == 32 && (ctx->cnn_fast32 == 2 || (ctx->cnn_fast32 == 1 && sizeof(T) == 8)))
+  if (a.prog.H == 32 && a.prog.W == 32 && (ctx->cnn_fast32 == 2 || (ctx->cnn_fast32 == 1 && sizeof(T) == 8))) {
+    // a 4x4 patch per lane where the patch rows are whole vectors (1 or 3 channels: MNIST- / CIFAR-shaped inputs)
+    // (cnn_t made the same choice: the tables and a.x1 / a.x2 are in patch order then)
+    if (a.prog.C == 3 && ctx->cnn_patch44) return launch_pair_form<T>(ctx, conv_pair44_kernel<T, ACT, 3>, a, blocks, 0);
+    if (a.prog.C == 1 && ctx->cnn_patch44) return launch_pair_form<T>(ctx, conv_pair44_kernel<T, ACT, 1>, a, blocks, 0);
     return launch_pair_form<T>(ctx, conv_pair32_kernel<T, ACT>, a, blocks, 0);
+  }
 #define PAIR_CASE(NP)                                                                                         \
   if (hw <= 64 * NP) {                                                                                        \
     if (hw == 64 * NP && 64 % a.prog.W == 0)                                                                  \
@@ -440,26 +632,32 @@ int cnn_t(smn_ctx* ctx, int act, int layers, double w, double b, double lw, cons
   const size_t lds_p = 4 * (psz + 2 * (W + 2) + 3) * sizeof(T);   // one padded map (+ dummy slot) per wave
   if (lds_q > 160 * 1024 || lds_p > 160 * 1024)
     return smn_fail(ctx, SMN_ENOTSUP, "smn_kernel_cnn: image %lldx%lld too large for the on-chip pair map", (long long)H, (long long)W);
-  // tables: R1 [n1][L][HW], diag1 [n1] (+ R2, diag2)
+  // tables: R1 [n1][L][HW], diag1 [n1] (+ R2, diag2); patch order + patch-order copies of the inputs for conv_pair44_kernel
+  const bool patch44 = H == 32 && W == 32 && (C == 1 || C == 3) && ctx->cnn_patch44 &&
+                       (ctx->cnn_fast32 == 2 || (ctx->cnn_fast32 == 1 && sizeof(T) == 8));
   const size_t qn1 = (size_t)n1 * (size_t)(layers > 0 ? layers : 1) * HW, qn2 = sym ? 0 : (size_t)n2 * (size_t)(layers > 0 ? layers : 1) * HW;
+  const size_t xn1 = patch44 ? (size_t)n1 * HW * C : 0, xn2 = (patch44 && !sym) ? (size_t)n2 * HW * C : 0;
   void* tv = nullptr;
-  SMN_TRY(smn_workspace(ctx, 1, sizeof(T) * (qn1 + qn2 + (size_t)n1 + (size_t)n2), &tv));
+  SMN_TRY(smn_workspace(ctx, 1, sizeof(T) * (qn1 + qn2 + (size_t)n1 + (size_t)n2 + xn1 + xn2) + 64, &tv));
   T* R1 = static_cast<T*>(tv);
   T* R2 = sym ? R1 : R1 + qn1;
   T* d1 = R1 + qn1 + qn2;
   T* d2 = d1 + n1;
+  T* xp1 = reinterpret_cast<T*>((reinterpret_cast<uintptr_t>(d2 + n2) + 15) & ~(uintptr_t)15);   // 16-byte aligned
+  T* xp2 = sym ? xp1 : xp1 + xn1;
   {
     ProfScope ps(ctx, PROF_PREP, ctx->stream);
     SMN_TRY(smn_allow_lds(ctx, reinterpret_cast<const void*>(conv_q_kernel<T>), lds_q));
     hipLaunchKernelGGL(conv_q_kernel<T>, dim3((unsigned)n1), dim3(256), lds_q, ctx->stream,
-                       static_cast<const T*>(x1), n1, p, R1, d1);
+                       static_cast<const T*>(x1), n1, p, R1, d1, patch44 ? 1 : 0, patch44 ? xp1 : nullptr);
     if (!sym)
       hipLaunchKernelGGL(conv_q_kernel<T>, dim3((unsigned)n2), dim3(256), lds_q, ctx->stream,
-                         static_cast<const T*>(x2), n2, p, R2, d2);
+                         static_cast<const T*>(x2), n2, p, R2, d2, patch44 ? 1 : 0, patch44 ? xp2 : nullptr);
   }
   SMN_CHECK_LAUNCH(ctx);
   PairArgs<T> a;
   a.x1 = static_cast<const T*>(x1); a.x2 = sym ? a.x1 : static_cast<const T*>(x2);
+  if (patch44) { a.x1 = xp1; a.x2 = xp2; }
   a.R1 = R1; a.R2 = R2; a.diag = d1; a.n1 = n1; a.n2 = n2;
   a.symmetric = sym ? 1 : 0; a.mirror = (sym && fill == SMN_FILL_FULL) ? 1 : 0;
   a.prog = p; a.out = static_cast<T*>(out); a.ldo = ldk;

@@ -66,6 +66,7 @@ struct smn_ctx {
   bool lds_attrs_done[2] = {false, false};   // hipFuncSetAttribute(MaxDynamicSharedMemorySize) issued for f32 / f64 kernels
   bool panel_leaf = true;            // panelr_kernel (register-resident 16x16 leaf) in the factorisation; env SMN_PANEL_LEAF=0: panel_kernel
   int cnn_fast32 = 1;                // conv-NNGP: register-only 3x3 stencil for 32x32 images (env SMN_CNN_FAST32: 0 never, 1 fp64 only, 2 both)
+  bool cnn_patch44 = true;           // conv-NNGP, 32x32 images with 1 or 3 channels: 4x4 pixel patch per lane (env SMN_CNN_PATCH44=0: one row pair per half-wave)
   int cnn_tiled = 1;                 // conv-NNGP pair kernel: XCD-tiled pair order for large problems (env SMN_CNN_TILED: 0 never, 2 always)
   bool rec_sym = true;               // stand-alone recursion: lower-tile + mirror kernel when symmetric (env SMN_REC_SYM=0)
   bool persistent_trail = true;      // persistent trailing-update kernel (env SMN_PERSISTENT=0 disables)

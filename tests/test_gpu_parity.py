@@ -497,6 +497,47 @@ def test_cnn_kernel_feeds_the_same_inference_heads():
     assert relerr_norm(np.asarray(mean), rm) < 1e-7 and relerr_norm(np.asarray(cov), rc) < 1e-7
 
 
+def test_cifar_shaped_conv_kernel_student_t_lml_and_test_nll_against_the_oracle():
+    """BASELINE config 3 at a size the oracle finishes in seconds: 176 training + 24 test images of 32x32x3 (the shape
+    that takes the 4x4-patch-per-lane pair kernel and its patch-order tables), fp64, 4 conv layers.  The whole chain --
+    conv-NNGP kernel -> Student-t log-marginal likelihood (smn_lml with df > 0) and SPR.test_nll (posterior through the
+    joint conv kernel + the b/a K + 1e-6 I quadratic form) -- against O.cnn_kernel + O.mvt_logpdf and the oracle's
+    restatement of spax/models.py:100-120 / likelihoods.py:52-65 on those kernels."""
+    import scipy.linalg as sla_
+    from smnngp import nt_kernels
+    from smnngp.spax.kernels import NNGPKernel
+    from smnngp.spax.likelihoods import StudentTLikelihood
+    from smnngp.spax.models import SPR
+    rng = np.random.default_rng(303)
+    n, t, nl = 176, 24, 4
+    xa = rng.uniform(0.0, 1.0, (n + t, 32, 32, 3))
+    xa = (xa - np.array([0.4914, 0.4822, 0.4465])) / np.array([0.247, 0.243, 0.261])      # classification/data.py:138-139
+    x, xt = xa[:n], xa[n:]
+    y = (rng.integers(0, 10, n) == 3).astype(np.float64) - 0.1
+    yt = (rng.integers(0, 10, t) == 3).astype(np.float64) - 0.1
+    alpha, beta, eps = 2.0, 2.0, 1e-4
+    kw = dict(num_hiddens=nl, act="relu", w_std=1.3, b_std=0.2, last_w_std=1.0)
+    kall = O.cnn_kernel(xa, None, **kw)                                                   # one oracle pass: all blocks
+    k_dd, k_td, k_tt = kall[:n, :n], kall[n:, :n], kall[n:, n:]
+    # --- the kernel itself (patch-order path) and the Student-t LML on it
+    kfn = nt_kernels.get_cnn_kernel(nl, act="relu", w_std=1.3, b_std=0.2, last_w_std=1.0)
+    got = np.asarray(kfn(x, None, "nngp"))
+    assert relerr(got, k_dd) < RTOL[np.float64]
+    kernel = NNGPKernel(lambda w, b, l: nt_kernels.get_cnn_kernel(nl, act="relu", w_std=w, b_std=b, last_w_std=l), 1.3, 0.2, 1.0)
+    model = SPR(kernel, StudentTLikelihood(alpha, beta), x, y, 0.0, 1.0, eps=eps)
+    want_lp = O.mvt_logpdf(y, (beta / alpha) * (k_dd + eps * np.eye(n)), 2.0 * alpha)
+    assert abs(model.loss() - (-want_lp / n)) < 1e-7 * abs(want_lp / n)
+    # --- test_nll: posterior (relative ridge) + Student-t predictive with the K-without-eps quadratic form
+    mean, cov = O.predict(k_dd, k_td, k_tt, y[:, None], diag_reg=eps)
+    df = 2.0 * alpha
+    khat = (beta / alpha) * k_dd + 1e-6 * np.eye(n)
+    d = df + y @ sla_.cho_solve(sla_.cho_factor(khat, lower=True), y)
+    sigma = np.sqrt(np.diag(d / (df + n) * (beta / alpha) * cov))
+    want_nll = -float(np.mean(O.student_t_logpdf(yt, df + n, mean.ravel(), sigma)))
+    got_nll = model.test_nll(xt, yt)
+    assert abs(got_nll - want_nll) < 1e-5 * max(1.0, abs(want_nll))                      # cond ~1e9 quadratic form: DESIGN section 1
+
+
 # ----------------------------------------------------------------------------- factorisation
 def _spd(rng, n, dtype, cond=1e3):
     a = rng.standard_normal((n, n))
