@@ -256,130 +256,13 @@ struct RecArgs {
   const T* tab1; const T* tab2; int64_t ldt1, ldt2; const T* dg; const T* dgt;
   LayerProg prog; int exact_diag;
   T* out_k; T* out_t; int64_t ldo; int rows_per_block;
-  int sym_tiles;   // recursion_sym_kernel: one workgroup per lower 64x64 tile
+  int sym_tiles;   // recursion_sym_kernel: 1 one workgroup per LOWER 64x64 tile (+ mirror), 2 one per tile of the n1 x n2 rectangle
 };
 
-// Block = 4 waves; blockIdx.x -> strip of 64*VEC columns, blockIdx.y -> group of rows.  A wave
-// streams one row segment at a time with 16-byte loads/stores, the next row's load in flight under
-// the current row's math; column tables (one b128 per table per layer) and row tables (broadcast
-// reads) both live in LDS, so the layer loop touches no global memory.
-template <typename T, int NET, int ACT, bool NTK>
-__global__ void __launch_bounds__(256) recursion_kernel(RecArgs<T> a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int VEC = 16 / sizeof(T);
-  constexpr int COLS = 256 * VEC;   // the 4 waves sit side by side on ONE row: 4 KiB contiguous per row visit
-  using vec_t = typename Mfma<T>::vec_t;
-  const int tid = threadIdx.x;
-  const int nsets = a.prog.nsets;
-  const int64_t col0 = (int64_t)blockIdx.x * COLS;
-  const int RB = a.rows_per_block;
-  constexpr bool FAST = ElemProg<T, NET, ACT, NTK>::FAST;
-  const int trows = nsets * 2 + 1;        // + sigma (FAST); the slot is staged but unused otherwise
-  T* scol = reinterpret_cast<T*>(smem);   // [trows][COLS]
-  T* srow = scol + trows * COLS;          // [trows][RB]: row factors too, so no global load sits in the layer loop
-  const int64_t rbeg = (int64_t)blockIdx.y * RB;
-  const int64_t rend = min(rbeg + RB, a.n1);
-  for (int idx = tid; idx < trows * COLS; idx += 256) {
-    const int s2 = idx / COLS, c = idx % COLS;
-    const int g2 = s2 < nsets * 2 ? s2 : nsets * 2 + 1;
-    const int64_t gc = col0 + c;
-    scol[idx] = gc < a.n2 ? a.tab2[(int64_t)g2 * a.ldt2 + gc] : T(0);
-  }
-  for (int idx = tid; idx < trows * RB; idx += 256) {
-    const int s2 = idx / RB, r = idx % RB;
-    const int g2 = s2 < nsets * 2 ? s2 : nsets * 2 + 1;
-    srow[idx] = rbeg + r < rend ? a.tab1[(int64_t)g2 * a.ldt1 + rbeg + r] : T(0);
-  }
-  __syncthreads();
-  const ElemProg<T, NET, ACT, NTK> prog(a.prog);
-  const int64_t gc = col0 + tid * VEC;
-  const bool full = gc + VEC <= a.n2;
-  auto load_row = [&](int64_t row) {
-    vec_t v;
-    if (full) {
-      v = *reinterpret_cast<const vec_t*>(a.k0 + row * a.ldk0 + gc);
-    } else {
-#pragma unroll
-      for (int e = 0; e < VEC; ++e) v[e] = gc + e < a.n2 ? a.k0[row * a.ldk0 + gc + e] : T(0);
-    }
-    return v;
-  };
-  // NR rows per iteration: the column tables are read once per layer for both rows, and the NR * VEC
-  // independent element chains per lane give the VALU enough ILP at the 2-4 waves per SIMD the LDS
-  // tables leave room for.  The next NR rows are in flight under the current ones.  (RB % NR == 0.)
-  constexpr int NR = 2;
-  vec_t nx[NR];
-#pragma unroll
-  for (int r = 0; r < NR; ++r) nx[r] = rbeg + r < rend ? load_row(rbeg + r) : vec_t{};
-  for (int64_t row = rbeg; row < rend; row += NR) {
-    vec_t kv[NR], hv[NR];
-#pragma unroll
-    for (int r = 0; r < NR; ++r) kv[r] = nx[r];
-#pragma unroll
-    for (int r = 0; r < NR; ++r)
-      if (row + NR + r < rend) nx[r] = load_row(row + NR + r);
-    const int lr = (int)(row - rbeg);
-#pragma unroll
-    for (int r = 0; r < NR; ++r)
-#pragma unroll
-      for (int e = 0; e < VEC; ++e) {
-        T k = kv[r][e], h = T(0);
-        prog.pre(k, h);
-        kv[r][e] = k;
-        hv[r][e] = h;
-      }
-    for (int s = 0; s < nsets; ++s) {
-      const vec_t cr = *reinterpret_cast<const vec_t*>(scol + (2 * s) * COLS + tid * VEC);
-      const vec_t cs = *reinterpret_cast<const vec_t*>(scol + (2 * s + 1) * COLS + tid * VEC);
-#pragma unroll
-      for (int r = 0; r < NR; ++r) {
-        const T ri = srow[(2 * s) * RB + lr + r];
-        const T si = srow[(2 * s + 1) * RB + lr + r];
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-          T k = kv[r][e], h = hv[r][e];
-          prog.step(s, k, h, ri * cr[e], si * cs[e]);
-          kv[r][e] = k;
-          hv[r][e] = h;
-        }
-      }
-    }
-    vec_t sgc = vec_t{};
-    if (FAST) sgc = *reinterpret_cast<const vec_t*>(scol + (2 * nsets) * COLS + tid * VEC);
-#pragma unroll
-    for (int r = 0; r < NR; ++r) {
-      const int64_t rr = row + r;
-      if (rr >= rend) break;
-      const T sgr = FAST ? srow[(2 * nsets) * RB + lr + r] : T(0);
-#pragma unroll
-      for (int e = 0; e < VEC; ++e) {
-        T k = kv[r][e], h = hv[r][e];
-        prog.post(k, h, sgr * sgc[e]);
-        if (a.exact_diag && rr == gc + e) {
-          k = a.dg[rr];
-          if (NTK) h = a.dgt[rr];
-        }
-        kv[r][e] = k;
-        hv[r][e] = h;
-      }
-      if (full) {
-        if (a.out_k) *reinterpret_cast<vec_t*>(a.out_k + rr * a.ldo + gc) = kv[r];
-        if (NTK && a.out_t) *reinterpret_cast<vec_t*>(a.out_t + rr * a.ldo + gc) = hv[r];
-      } else {
-#pragma unroll
-        for (int e = 0; e < VEC; ++e)
-          if (gc + e < a.n2) {
-            if (a.out_k) a.out_k[rr * a.ldo + gc + e] = kv[r][e];
-            if (NTK && a.out_t) a.out_t[rr * a.ldo + gc + e] = hv[r][e];
-          }
-      }
-    }
-  }
-}
-
-// Symmetric form (x2 == x1, full output): one workgroup per LOWER 64x64 tile.  The element chains run once per
-// unordered pair; the tile is written straight (16-byte stores) and, through an LDS transpose, mirrored into
-// the upper triangle.  Halves the VALU work that bounds the 4-layer map and the K0 bytes read.
+// Stand-alone layer recursion over a stored K0, one workgroup per 64x64 tile, column and row tables in LDS.
+// Symmetric form (x2 == x1, full output): LOWER tiles only.  The element chains run once per unordered pair; the tile is
+// written straight (16-byte stores) and, through an LDS transpose, mirrored into the upper triangle.  Halves the VALU work
+// that bounds the 4-layer map and the K0 bytes read.  Cross form (sym_tiles == 2): every tile of the rectangle, no mirror.
 template <typename T, int NET, int ACT, bool NTK>
 __global__ void __launch_bounds__(256) recursion_sym_kernel(RecArgs<T> a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -397,12 +280,24 @@ __global__ void __launch_bounds__(256) recursion_sym_kernel(RecArgs<T> a) {
   T* srow = scol + trows * TS;                   // [trows][TS] factors of the tile's rows
   T* tbk = srow + trows * TS;                    // [TS][LDT] tile of K for the mirror
   T* tbt = tbk + TS * LDT;                       // [TS][LDT] tile of Theta (NTK only)
+  // Cross kernels (x1 != x2) take the same tile shape over the whole n1 x n2 rectangle: every 16-byte load of a 64x64 tile in
+  // flight before the tables are staged, 8 workgroups per CU (the r01 strip kernel had two loads per lane in flight and read
+  // at 51 % of the HBM rate where the map itself is cheap: profiles/r03_recursion_table.txt).
+  const bool rect = a.sym_tiles == 2;
   int tr, tc;
-  tri_decode(blockIdx.x, tr, tc);
-  const int64_t row0 = (int64_t)tr * TS, col0 = (int64_t)tc * TS, n = a.n1;
+  if (rect) {
+    const int tn = (int)((a.n2 + TS - 1) / TS);
+    tr = (int)(blockIdx.x / tn);
+    tc = (int)(blockIdx.x % tn);
+  } else {
+    tri_decode(blockIdx.x, tr, tc);
+  }
+  const int64_t row0 = (int64_t)tr * TS, col0 = (int64_t)tc * TS, n = a.n1, nc = rect ? a.n2 : a.n1;
+  const T* tabc = rect ? a.tab2 : a.tab1;
+  const int64_t ldtc = rect ? a.ldt2 : a.ldt1;
   const int lr0 = tid / LPR, lc = (tid % LPR) * VEC;
   const int64_t gc = col0 + lc;
-  const bool cfull = gc + VEC <= n;
+  const bool cfull = gc + VEC <= nc;
   vec_t kv[NP], hv[NP];
 #pragma unroll
   for (int p = 0; p < NP; ++p) {                 // every load of the tile in flight before the tables are staged
@@ -411,18 +306,19 @@ __global__ void __launch_bounds__(256) recursion_sym_kernel(RecArgs<T> a) {
       kv[p] = *reinterpret_cast<const vec_t*>(a.k0 + gr * a.ldk0 + gc);
     } else {
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) kv[p][e] = (gr < n && gc + e < n) ? a.k0[gr * a.ldk0 + gc + e] : T(0);
+      for (int e = 0; e < VEC; ++e) kv[p][e] = (gr < n && gc + e < nc) ? a.k0[gr * a.ldk0 + gc + e] : T(0);
     }
   }
   for (int idx = tid; idx < trows * TS; idx += 256) {
     const int s2 = idx / TS, r = idx % TS;
     const int g2 = s2 < nsets * 2 ? s2 : nsets * 2 + 1;
-    scol[idx] = col0 + r < n ? a.tab1[(int64_t)g2 * a.ldt1 + col0 + r] : T(0);
+    scol[idx] = col0 + r < nc ? tabc[(int64_t)g2 * ldtc + col0 + r] : T(0);
     srow[idx] = row0 + r < n ? a.tab1[(int64_t)g2 * a.ldt1 + row0 + r] : T(0);
   }
   __syncthreads();
   const ElemProg<T, NET, ACT, NTK> prog(a.prog);
-  const bool mirror = tr != tc;
+  const bool mirror = !rect && tr != tc;
+  const bool diag_exact = rect ? a.exact_diag != 0 : true;
 #pragma unroll
   for (int pp = 0; pp < NP; pp += 2) {           // two passes at a time: 2 * VEC independent chains per lane
 #pragma unroll
@@ -461,7 +357,7 @@ __global__ void __launch_bounds__(256) recursion_sym_kernel(RecArgs<T> a) {
       for (int e = 0; e < VEC; ++e) {
         T k = kv[pp + r][e], h = hv[pp + r][e];
         prog.post(k, h, sgr * sgc[e]);
-        if (gr == gc + e) {
+        if (diag_exact && gr == gc + e) {
           k = a.dg[gr < n ? gr : 0];
           if (NTK) h = a.dgt[gr < n ? gr : 0];
         }
@@ -479,7 +375,7 @@ __global__ void __launch_bounds__(256) recursion_sym_kernel(RecArgs<T> a) {
         } else {
 #pragma unroll
           for (int e = 0; e < VEC; ++e)
-            if (gc + e < n) {
+            if (gc + e < nc) {
               if (a.out_k) a.out_k[gr * a.ldo + gc + e] = kv[pp + r][e];
               if (NTK && a.out_t) a.out_t[gr * a.ldo + gc + e] = hv[pp + r][e];
             }
@@ -658,19 +554,11 @@ int run_build_t(smn_ctx* ctx, const BuildCall& c) {
 
 template <typename T, int NET, int ACT, bool NTK>
 int launch_rec_t(smn_ctx* ctx, const RecArgs<T>& a, dim3 grid, size_t lds) {
-  if (a.sym_tiles) {
-    auto kern = recursion_sym_kernel<T, NET, ACT, NTK>;
-    SMN_TRY(smn_allow_lds(ctx, reinterpret_cast<const void*>(kern), lds));
-    {
-      ProfScope ps(ctx, PROF_RECURSION, ctx->stream);
-      hipLaunchKernelGGL(kern, grid, dim3(256), lds, ctx->stream, a);
-    }
-    SMN_CHECK_LAUNCH(ctx);
-    return SMN_OK;
-  }
+  auto kern = recursion_sym_kernel<T, NET, ACT, NTK>;
+  SMN_TRY(smn_allow_lds(ctx, reinterpret_cast<const void*>(kern), lds));
   {
     ProfScope ps(ctx, PROF_RECURSION, ctx->stream);
-    hipLaunchKernelGGL((recursion_kernel<T, NET, ACT, NTK>), grid, dim3(256), lds, ctx->stream, a);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, ctx->stream, a);
   }
   SMN_CHECK_LAUNCH(ctx);
   return SMN_OK;
@@ -732,26 +620,19 @@ int recursion_t(smn_ctx* ctx, const BuildSpec& spec, const void* k0, int64_t n1,
   a.prog = prog; a.exact_diag = symmetric;
   a.out_k = (get_mask & SMN_GET_NNGP) ? static_cast<T*>(nngp) : nullptr;
   a.out_t = want_ntk ? static_cast<T*>(ntk) : nullptr;
-  a.ldo = ldk; a.rows_per_block = 32;
-  constexpr int COLS = 256 * (16 / sizeof(T));
-  dim3 grid((unsigned)((n2 + COLS - 1) / COLS), (unsigned)((n1 + a.rows_per_block - 1) / a.rows_per_block));
-  const size_t lds = (size_t)(prog.nsets * 2 + 1) * (COLS + a.rows_per_block) * sizeof(T);
+  a.ldo = ldk; a.rows_per_block = 0;
   // 16-byte vector path needs aligned rows
   if (ldk0 % (16 / sizeof(T)) || ldk % (16 / sizeof(T)) || (reinterpret_cast<uintptr_t>(k0) & 15) ||
       (a.out_k && (reinterpret_cast<uintptr_t>(a.out_k) & 15)) || (a.out_t && (reinterpret_cast<uintptr_t>(a.out_t) & 15)))
     return smn_fail(ctx, SMN_EINVAL, "smn_recursion: k0/out must be 16-byte aligned with ld %% %d == 0", (int)(16 / sizeof(T)));
-  a.sym_tiles = 0;
-  if (symmetric && n1 == n2 && ctx->rec_sym) {
-    constexpr int TS = 64;
-    const int64_t t = (n1 + TS - 1) / TS;
-    const int64_t ntiles = t * (t + 1) / 2;
-    if (ntiles < (int64_t)INT32_MAX) {
-      a.sym_tiles = 1;
-      const size_t slds = sizeof(T) * ((size_t)(prog.nsets * 2 + 1) * 2 * TS + (size_t)(want_ntk ? 2 : 1) * TS * (TS + 1));
-      return launch_rec<T>(ctx, a, dim3((unsigned)ntiles), slds, want_ntk);
-    }
-  }
-  return launch_rec<T>(ctx, a, grid, lds, want_ntk);
+  constexpr int TS = 64;
+  const int64_t t1 = (n1 + TS - 1) / TS, t2 = (n2 + TS - 1) / TS;
+  const bool lower = symmetric && n1 == n2 && ctx->rec_sym;   // SMN_REC_SYM=0: the symmetric input as a rectangle too (A/B)
+  const int64_t ntiles = lower ? t1 * (t1 + 1) / 2 : t1 * t2;
+  if (ntiles >= (int64_t)INT32_MAX) return smn_fail(ctx, SMN_ENOTSUP, "smn_recursion: too many tiles");
+  a.sym_tiles = lower ? 1 : 2;
+  const size_t slds = sizeof(T) * ((size_t)(prog.nsets * 2 + 1) * 2 * TS + (lower ? (size_t)(want_ntk ? 2 : 1) * TS * (TS + 1) : 0));
+  return launch_rec<T>(ctx, a, dim3((unsigned)ntiles), slds, want_ntk);
 }
 
 }  // namespace

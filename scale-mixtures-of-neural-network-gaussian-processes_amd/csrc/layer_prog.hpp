@@ -15,6 +15,9 @@
 // It is the same arithmetic (c_l is exactly the argument the generic map forms) with 5 ops less per layer
 // and a single-sqrt J (nngp_math.hpp).  The table slots hold (u, v) instead of (r, s) and sigma rides in
 // the NTK-diagonal slot; diag_tables_kernel writes whichever the flag asks for.
+// (Round 3 tried the same form for erf -- x_{l+1} = asin(c_l), u^0 = sqrt(2) w r^0, u^l = (2/sqrt(pi)) w r^l, v^l = sqrt(2) b r^l,
+// sigma = last_w sqrt(2/pi): 4 ops less per layer of ~24, no measurable gain (symmetric L = 6: 0.53 -> 0.55 ms) and, asin being
+// steep at |c| -> 1, 1e-4 disagreements with the generic path in f32.  Not kept.)
 #pragma once
 #include "nngp_math.hpp"
 
