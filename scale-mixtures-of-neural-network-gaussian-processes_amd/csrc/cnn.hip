@@ -46,6 +46,9 @@ struct ConvProg {
 // bound by streaming these tables out of L2, not by its arithmetic:
 //   ReLU: r = 1/sqrt(q~) (0 where q~ <= 0); the second factor s_i s_j = sqrt(q_i q_j)/(2 pi) = 1/(2 pi r_i r_j)
 //   erf:  r = 1/sqrt(1 + 2 q~)
+// (A second table s = sqrt(q~ / 2 pi), so that s_i s_j is one multiplication instead of 1 / (2 pi r_i r_j) with a reciprocal, a
+// Newton step and a select, was tried in round 3: 6 vector instructions fewer per pixel and layer, but 64 more registers for the
+// table vectors of a layer -- 2 waves per SIMD instead of 3 -- and the kernel build went from 572 to 1003 ms.  Not kept.)
 // patch44 != 0 (32x32 images, conv_pair44_kernel): R is written in the order that kernel's lanes read it -- for layer l the
 // vectors [j = 4-pixel patch row r x vector v][lane = patch (py, px)][16 bytes], so one load instruction of a wave is 1 KB of
 // consecutive bytes -- and xperm receives the image in the same order ([vector of a patch row][lane][16 bytes], a patch
@@ -421,7 +424,9 @@ __global__ void __launch_bounds__(256, SMN_CNN32_OCC) conv_pair32_kernel(PairArg
 // 16 halo values from the four neighbouring lanes, fetched by ds_bpermute_b32 (the LDS crossbar: no LDS memory, no vector-ALU
 // instruction).  Border patches multiply their missing halo by a 0 / 1 factor folded into the addition (an fma).  The loads
 // are whole 16-byte vectors as well: a patch row is 4 consecutive pixels, so its C channels and its factor-table entries
-// are contiguous.  One reciprocal step less for 1 / (r_i r_j) (v_rcp_f64 + one Newton step: 2^-50, against 2 steps).
+// are contiguous -- and fully coalesced: conv_q_kernel writes the factor tables and a copy of the images in exactly the order the
+// lanes read them ([vector of a patch row][lane][16 bytes]).  One reciprocal step less for 1 / (r_i r_j) (v_rcp_f64 + one Newton
+// step: 2^-50, against 2 steps).  (A degree-12 J(c), 1.1e-13 and 5 fused multiply-adds fewer, measured no gain: 579 against 572 ms.)
 typedef float cnn_f32x4 __attribute__((ext_vector_type(4)));
 typedef double cnn_f64x2 __attribute__((ext_vector_type(2)));
 template <typename T>
@@ -434,6 +439,7 @@ template <>
 __device__ __forceinline__ double lane_fetch<double>(double v, int sb) {
   return __hiloint2double(__builtin_amdgcn_ds_bpermute(sb, __double2hiint(v)), __builtin_amdgcn_ds_bpermute(sb, __double2loint(v)));
 }
+
 __device__ __forceinline__ float rcp_fast(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ double rcp_fast(double x) {
   const double r = __builtin_amdgcn_rcp(x);
@@ -519,6 +525,12 @@ __global__ void __launch_bounds__(256, SMN_CNN32_OCC) conv_pair44_kernel(PairArg
         h[r][0] = fma(ml, hl[r], s01);
         h[r][3] = fma(mr, hr[r], s23);
       }
+      // the table products of the 16 pixels, formed once the loads have landed: 8 vectors per table die here
+      T rr[4][4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) rr[r][c] = t1[r][c / VEC][c % VEC] * t2[r][c / VEC][c % VEC];
       // vertical 3-sums; the halo rows come from the lanes above and below
       T ht[4], hb[4];
 #pragma unroll
@@ -537,13 +549,12 @@ __global__ void __launch_bounds__(256, SMN_CNN32_OCC) conv_pair44_kernel(PairArg
 #endif
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const T rr = t1[r][c / VEC][c % VEC] * t2[r][c / VEC][c % VEC];
           const T kt = fma(w2_9, bs[r], b2);
           if (ACT == 0) {
-            const T ss = rr > T(0) ? T(1.0 / (2.0 * nngp::kPi)) * rcp_fast(rr) : T(0);
-            val[r][c] = nngp::relu_map<T, false>(kt, rr, ss).k;
+            const T ss = rr[r][c] > T(0) ? T(1.0 / (2.0 * nngp::kPi)) * rcp_fast(rr[r][c]) : T(0);
+            val[r][c] = nngp::relu_map<T, false>(kt, rr[r][c], ss).k;
           } else {
-            val[r][c] = nngp::erf_map<T, false>(kt, rr, T(0)).k;
+            val[r][c] = nngp::erf_map<T, false>(kt, rr[r][c], T(0)).k;
           }
         }
       }

@@ -100,6 +100,8 @@ while time.time() < t_end:
             n, m = int(rng.integers(1, 24)), int(rng.integers(1, 12))
             h, wd, c = int(rng.integers(1, 20)), int(rng.integers(1, 20)), int(rng.integers(1, 5))
             resn = rng.integers(2) == 1
+            if not resn and rng.integers(3) == 0:   # r03: the 32x32 kernels (4x4 patch per lane for 1 / 3 channels, row pairs otherwise)
+                h = wd = 32; n, m = int(rng.integers(1, 9)), int(rng.integers(1, 6)); L = int(rng.integers(1, 5))
             if resn:
                 h, wd = 8 * int(rng.integers(1, 4)), 8 * int(rng.integers(1, 4)); L = int(rng.integers(1, 3))
             case = (kind, dt.__name__, "resnet" if resn else "cnn", act, L, n, m, h, wd, c, w, b, lw)
