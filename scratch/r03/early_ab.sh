@@ -1,6 +1,6 @@
+#!/bin/bash
 # r03 experiment (not shipped): applies the early-pass variant of panelr_kernel to cholesky.hip; A/B in profiles/r03_panel_early_pass_ab.txt
 # (build the variants with build.build(variant="emN", defines=("-DSMN_PANEL_EARLY_MFMA=N",)) first)
-#!/bin/bash
 # r03: helper waves on a free SIMD pre-apply the K < cb part of the next block's update beside the leaf: budget sweep
 P=scale-mixtures-of-neural-network-gaussian-processes_amd
 mkdir -p gpurun_out
