@@ -438,6 +438,41 @@ def measure_predict(L, ctx, n, d, nl, act, t, steps, warmup):
     return out
 
 
+def measure_loss_grad(L, ctx, n, d, nl, act, steps, warmup):
+    """One analytic loss + gradient call (SPR.loss_and_grad: what objax.GradValues(model.loss, vars) provides at
+    experiments/regression/train.py:61-67) beside SPR.loss at the same size, Student-t head.  The gradient needs K~^-1 in
+    full: N^3 flops of factorisation work against the loss's N^3/3."""
+    from smnngp import nt_kernels
+    from smnngp.spax.kernels import NNGPKernel
+    from smnngp.spax.likelihoods import StudentTLikelihood
+    from smnngp.spax.models import SPR
+    rng = np.random.default_rng(0)
+    xd = ctx.to_device(rng.standard_normal((n, d)).astype(np.float32))
+    yh = rng.standard_normal(n).astype(np.float32)
+    kernel = NNGPKernel(lambda w, b, l: nt_kernels.get_mlp_kernel(nl, act=act, w_std=w, b_std=b, last_w_std=l), 1.0, 0.3, 1.0)
+    model = SPR(kernel, StudentTLikelihood(2.0, 2.0), xd, yh, 0.0, 1.0, eps=1e-2)
+    res = {}
+    for name, fn in (("loss", model.loss), ("loss_and_grad", model.loss_and_grad)):
+        for _ in range(warmup):
+            fn()
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            val = fn()
+        ctx.synchronize()
+        res[name] = ((time.perf_counter() - t0) / steps * 1e3, val)
+    flops = 2.0 * n * n * d + float(n) ** 3                               # Gram + (factor, L^-1, L^-T L^-1)
+    ms = res["loss_and_grad"][0]
+    loss, grads = res["loss_and_grad"][1]
+    return {"workload": "SPR.loss_and_grad: N=%d d=%d L=%d %s f32, Student-t head, gradients of w_std, b_std, last_w_std, eps, a, b" % (n, d, nl, act),
+            "ms_per_step": ms, "loss_ms": res["loss"][0], "loss_evaluations": ms / res["loss"][0],
+            "loss": float(loss), "grad_w_std": float([v for k, v in grads.items() if k.endswith("w_std") and "last" not in k][0]),
+            "flops_counted": flops, "flops_note": "2 N^2 d + N^3 (factorisation N^3/3, L^-T N^3/3, L^-T L^-1 N^3/3; the contraction pass not counted)",
+            "roofline": {"kernel": "augmented factorisation [[K~, .], [I, 0]] with the identity block's structural zeros left out of every launch",
+                         "bound": "mfma", "achieved": flops / (ms * 1e-3) / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": flops / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS}}
+
+
 def other_workloads(L, ctx, budget_s=330.0):
     """BASELINE.json's other single-GPU configurations and the predictive path, measured in this process after the
     headline (each in its own try: a failing or skipped workload never breaks the bench line)."""
@@ -446,6 +481,7 @@ def other_workloads(L, ctx, budget_s=330.0):
     plan = [
         ("c2", lambda: measure_mlp_loss(L, ctx, 4096, 512, 3, "relu", "f32", 1e-3, 20, 3)),
         ("predict_c4", lambda: measure_predict(L, ctx, 16384, 3072, 4, "relu", 2048, 3, 1)),
+        ("grad_c4", lambda: measure_loss_grad(L, ctx, 16384, 3072, 4, "relu", 3, 1)),
         ("f64_n8192", lambda: measure_mlp_loss(L, ctx, 8192, 3072, 4, "relu", "f64", 1e-6, 5, 1)),
         ("c5", lambda: measure_mlp_loss(L, ctx, 32768, 1024, 6, "erf", "f32", 1e-3, 4, 1)),
         ("c3", lambda: measure_conv(L, ctx, 10000, 4, "relu", 1e-4, 2, 1)),

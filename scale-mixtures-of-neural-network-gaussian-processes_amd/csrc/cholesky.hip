@@ -687,9 +687,6 @@ template <typename T>
 struct UpdArgs {
   T* a; int64_t lda; int64_t r0, c0, k0; int K; int tiles_n; int lower;
   int use_map; TileMap map;   // XCD-aware patch order (gemm_nt.hpp) instead of the linear one
-  // identity rows [id0, id1) (id0 < 0: none): a tile whose rows lie inside them and start right of the K range
-  // multiplies zeros -- the workgroup leaves at once
-  int64_t id0, id1;
 };
 
 template <typename T>
@@ -767,7 +764,6 @@ __global__ void __launch_bounds__(256, BN == 64 ? 4 : (BM == 64 ? (sizeof(T) == 
     upd_decode(u, (int)blockIdx.x, tr, tc);
   }
   const int64_t row0 = u.r0 + (int64_t)tr * BM + qr, col0 = u.c0 + (int64_t)tc * kTile + qc;
-  if (u.id0 >= 0 && row0 >= u.id0 && row0 + BM <= u.id1 && row0 - u.id0 >= u.k0 + u.K) return;
   Tile t;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wr = wave >> 1, wc = wave & 1;
@@ -936,12 +932,35 @@ int launch_update(smn_ctx* ctx, hipStream_t st, T* a, int64_t lda, int64_t r0, i
                   int64_t tiles_m, int64_t tiles_n, int lower, int tag = -1) {
   if (tiles_m <= 0 || tiles_n <= 0 || K <= 0) return SMN_OK;
   if (tag < 0) tag = lower ? 1 : 0;   // 0: strip update, 1: trailing update (separate symbols / profile categories)
+  if (ctx->chol_id0 >= 0) {
+    // Identity rows [id0, id1) (analytic gradients): row id0 + i of the panel is zero left of column i, so the rows from
+    // id0 + k0 + K on multiply zeros in this update -- as row operand AND as column operand.  What is left is the
+    // contiguous rows [r0, act) in the caller's shape plus the rows below the identity block (the right-hand sides)
+    // against the live columns; launched as such (the same tiles, the same arithmetic), not as one grid whose dead
+    // workgroups leave at once: the XCD-aware tile order hands every XCD one contiguous eighth of the grid, and the dead
+    // tiles are the last 70 % of it (profiles/r03_grad_identity_skip.txt: 3 of 8 XCDs were doing all the work).
+    const int64_t id0 = ctx->chol_id0, id1 = ctx->chol_id1, r_end = r0 + tiles_m * kTile;
+    const int64_t act = std::min(id1, id0 + (k0 + K + kTile - 1) / kTile * kTile);
+    if (act < id1 && r_end > act) {
+      ctx->chol_id0 = -1;
+      int rc = SMN_OK;
+      if (r0 < act) rc = launch_update<T>(ctx, st, a, lda, r0, c0, k0, K, (act - r0) / kTile, tiles_n, lower, tag);
+      if (rc == SMN_OK && r_end > id1) {
+        const int64_t tb = (r_end - id1) / kTile;
+        // live columns of those rows: the caller's own (strip, trapezoid: all left of id0) or, for a triangle, [c0, act)
+        const int64_t nb = lower == 1 ? (act - c0) / kTile : tiles_n;
+        rc = launch_update<T>(ctx, st, a, lda, id1, c0, k0, K, tb, nb, 0, tag);
+        if (rc == SMN_OK && lower == 1) rc = launch_update<T>(ctx, st, a, lda, id1, id1, k0, K, tb, tb, 1, tag);
+      }
+      ctx->chol_id0 = id0;
+      return rc;
+    }
+  }
   if (lower == 2 && tiles_n >= tiles_m) {   // a trapezoid as wide as it is tall is the triangle
     lower = 1;
     tiles_n = tiles_m;
   }
-  UpdArgs<T> u{a, lda, r0, c0, k0, (int)K, (int)tiles_n, lower, 0, TileMap::make(tiles_m, tiles_n, lower == 1),
-               ctx->chol_id0, ctx->chol_id1};
+  UpdArgs<T> u{a, lda, r0, c0, k0, (int)K, (int)tiles_n, lower, 0, TileMap::make(tiles_m, tiles_n, lower == 1)};
   int64_t nt = lower == 1   ? tiles_m * (tiles_m + 1) / 2
                : lower == 2 ? tiles_n * (tiles_n + 1) / 2 + (tiles_m - tiles_n) * tiles_n
                             : tiles_m * tiles_n;
@@ -954,8 +973,7 @@ int launch_update(smn_ctx* ctx, hipStream_t st, T* a, int64_t lda, int64_t r0, i
   if constexpr (sizeof(T) == 4) {
     // CUs this stream may use: the bulk stream of the look-ahead is masked off the chain's CUs
     const int cus = (st == ctx->stream_bulk && st != nullptr) ? ctx->num_cu - ctx->chain_cus : ctx->num_cu;
-    if (tag == 1 && lower && !u.use_map && ctx->persistent_trail && nt > 2 * cus && K <= kPersistMaxK &&
-        ctx->chol_id0 < 0) {   // the persistent walk has no tile skipping
+    if (tag == 1 && lower && !u.use_map && ctx->persistent_trail && nt > 2 * cus && K <= kPersistMaxK) {
       // persistent walk over the lower tiles, two workgroups per CU
       const size_t plds = TileNT<T, kTile, kTile, 2>::LDS_BYTES;
       ProfScope ps(ctx, PROF_TRAIL, st);

@@ -193,12 +193,6 @@ __global__ void cast_q_kernel(const T* __restrict__ s, double* __restrict__ d, i
   if (i < n) d[i] = (double)s[i];
 }
 
-template <typename T>
-__global__ void identity_block_kernel(T* __restrict__ a, int64_t lda, int64_t n) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) a[i * lda + i] = T(1);
-}
-
 template <typename T, int NET, int ACT>
 int grad_terms_na(smn_ctx* ctx, const GradArgs<T>& a, const double* q64, int64_t ntiles, double* out_d) {
   hipLaunchKernelGGL((grad_tables_kernel<NET, ACT>), dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0, ctx->stream,
@@ -274,8 +268,8 @@ extern "C" int smn_lml_grad_terms(smn_ctx* ctx, int dtype, int net, int act, int
                              alpha_d, coef, terms_h);
 }
 
-// Fused: K0 = X X^T / d and its diagonal, K by the stand-alone recursion into the joint matrix
-// [[K, .], [I, 0]], ONE augmented factorisation (alpha, -K~^-1, quad, logdet), then the contraction.
+// Fused: K0 = X X^T / d and its diagonal, K by the stand-alone recursion straight into the factorisation workspace
+// laid out as [[K, .], [I, 0]], ONE augmented factorisation (alpha, -K~^-1, quad, logdet), then the contraction.
 extern "C" int smn_spr_loss_grad(smn_ctx* ctx, int dtype, int net, int act, int num_hiddens, double w_std,
                                  double b_std, double last_w_std, const void* x_d, int64_t n, int64_t ldx, int64_t d,
                                  const void* y_d, double eps_abs, double df, double scale, double* quad_h,
@@ -287,29 +281,18 @@ extern "C" int smn_spr_loss_grad(smn_ctx* ctx, int dtype, int net, int act, int 
   if (df > 0.0 && !(scale > 0.0)) return smn_fail(ctx, SMN_EINVAL, "smn_spr_loss_grad: scale must be > 0");
   const size_t es = dtype_size(dtype);
   const int64_t al = 16 / (int64_t)es;
-  const int64_t ld0 = round_up(n, al), n2 = 2 * n, ldj = round_up(n2, al);
-  void *k0 = nullptr, *joint = nullptr, *post = nullptr;
+  const int64_t ld0 = round_up(n, al);
+  void *k0 = nullptr, *post = nullptr;
   SMN_TRY(smn_workspace(ctx, 5, es * ((size_t)n * ld0 + (size_t)n), &k0));
-  SMN_TRY(smn_workspace(ctx, 6, es * (size_t)n2 * ldj, &joint));
   SMN_TRY(smn_workspace(ctx, 7, es * ((size_t)n * ld0 + (size_t)n), &post));
   void* q = static_cast<char*>(k0) + es * (size_t)n * ld0;
   void* ninv = post;
   void* alpha = static_cast<char*>(post) + es * (size_t)n * ld0;
   SMN_TRY(smn_gram(ctx, dtype, x_d, n, ldx, nullptr, 0, 0, d, k0, ld0, q, nullptr));
-  SMN_HIP(ctx, hipMemsetAsync(joint, 0, es * (size_t)n2 * ldj, ctx->stream));
-  SMN_TRY(smn_recursion(ctx, dtype, net, act, num_hiddens, w_std, b_std, last_w_std, k0, n, n, ld0, q, q, 1,
-                        SMN_GET_NNGP, joint, nullptr, ldj));
-  char* jb = static_cast<char*>(joint) + es * (size_t)n * ldj;   // rows n..2n: [I, 0]
-  if (dtype == SMN_F64)
-    hipLaunchKernelGGL(identity_block_kernel<double>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
-                       reinterpret_cast<double*>(jb), ldj, n);
-  else
-    hipLaunchKernelGGL(identity_block_kernel<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
-                       reinterpret_cast<float*>(jb), ldj, n);
-  SMN_CHECK_LAUNCH(ctx);
   double quad = 0.0, logdet = 0.0;
   int info = 0;
-  SMN_TRY(predict_joint(ctx, dtype, joint, n, n, ldj, y_d, 1, 0.0, eps_abs, alpha, ninv, ld0, &quad, &logdet, &info, true));
+  SMN_TRY(factor_with_identity(ctx, dtype, net, act, num_hiddens, w_std, b_std, last_w_std, k0, ld0, q, n, y_d, eps_abs, alpha,
+                               ninv, ld0, &quad, &logdet, &info));
   if (quad_h) *quad_h = quad;
   if (logdet_h) *logdet_h = logdet;
   if (info_h) *info_h = info;

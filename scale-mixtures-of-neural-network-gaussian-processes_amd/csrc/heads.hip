@@ -332,6 +332,39 @@ extern "C" int smn_lml_from_shards(smn_ctx* ctx, int dtype, int64_t n, const voi
   return SMN_OK;
 }
 
+namespace {
+
+template <typename T>
+__global__ void identity_block_kernel(T* __restrict__ a, int64_t lda, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) a[i * lda + i] = T(1);
+}
+
+}  // namespace
+
+// Analytic gradients (grad.hip): smn_predict's factorisation with K_td = I, K_tt = 0, the joint matrix assembled IN the
+// factorisation workspace -- the layer recursion of the Gram matrix k0 writes K there -- instead of being copied into it
+// from a second 2N x 2N matrix.  alpha = K~^-1 y comes back as the "mean", -K~^-1 as the "covariance".
+int factor_with_identity(smn_ctx* ctx, int dtype, int net, int act, int num_hiddens, double w_std, double b_std,
+                         double last_w_std, const void* k0_d, int64_t ldk0, const void* q_d, int64_t n, const void* y_d,
+                         double eps_abs, void* alpha_d, void* ninv_d, int64_t ldinv, double* quad_h, double* logdet_h,
+                         int* info_h) {
+  Aug g;
+  SMN_TRY(aug_alloc(ctx, dtype, n, n, 1, &g));
+  SMN_HIP(ctx, hipMemsetAsync(g.at(n, 0), 0, g.es * (size_t)(g.n_total - n) * (size_t)g.lda, ctx->stream));
+  SMN_TRY(smn_recursion(ctx, dtype, net, act, num_hiddens, w_std, b_std, last_w_std, k0_d, n, n, ldk0, q_d, q_d, 1,
+                        SMN_GET_NNGP, g.a, nullptr, g.lda));
+  if (dtype == SMN_F64)
+    hipLaunchKernelGGL(identity_block_kernel<double>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                       reinterpret_cast<double*>(g.at(g.n_pad, 0)), g.lda, n);
+  else
+    hipLaunchKernelGGL(identity_block_kernel<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                       reinterpret_cast<float*>(g.at(g.n_pad, 0)), g.lda, n);
+  SMN_CHECK_LAUNCH(ctx);
+  SMN_TRY(fill_identity_pad(ctx, dtype, g.a, g.lda, g.n_pad, n));
+  return aug_finish(ctx, dtype, g, y_d, 1, n, eps_abs, 0.0, alpha_d, ninv_d, ldinv, quad_h, logdet_h, info_h, true);
+}
+
 int predict_joint(smn_ctx* ctx, int dtype, void* kj_d, int64_t n, int64_t t, int64_t ldk, const void* y_d, int64_t c,
                   double ridge_rel, double ridge_abs, void* mean_d, void* cov_d, int64_t ldcov, double* quad_h,
                   double* logdet_h, int* info_h, bool td_identity) {

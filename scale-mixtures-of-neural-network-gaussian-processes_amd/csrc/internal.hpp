@@ -51,6 +51,11 @@ int cholesky_padded(smn_ctx* ctx, int dtype, void* a, int64_t n_total, int64_t n
 int predict_joint(smn_ctx* ctx, int dtype, void* kj_d, int64_t n, int64_t t, int64_t ldk, const void* y_d, int64_t c,
                   double ridge_rel, double ridge_abs, void* mean_d, void* cov_d, int64_t ldcov, double* quad_h,
                   double* logdet_h, int* info_h, bool td_identity);
+// the same factorisation with K_td = I, K_tt = 0 assembled in place from the Gram matrix k0 (heads.hip; analytic gradients)
+int factor_with_identity(smn_ctx* ctx, int dtype, int net, int act, int num_hiddens, double w_std, double b_std,
+                         double last_w_std, const void* k0_d, int64_t ldk0, const void* q_d, int64_t n, const void* y_d,
+                         double eps_abs, void* alpha_d, void* ninv_d, int64_t ldinv, double* quad_h, double* logdet_h,
+                         int* info_h);
 int fetch_logdet_info(smn_ctx* ctx, double* logdet, int* info);
 // logdet, info and nq device doubles (quadratic forms) through the pinned mailbox: one tiny kernel + ONE synchronisation
 int fetch_results(smn_ctx* ctx, const double* quad_dev, int nq, double* quad_h, double* logdet, int* info);
