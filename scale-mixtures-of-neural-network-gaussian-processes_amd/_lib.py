@@ -262,7 +262,19 @@ class DeviceArray:
         return a if dtype is None else a.astype(dtype)
 
     def diagonal(self):
-        return np.diagonal(self.numpy())
+        """The main diagonal, fetched as one strided copy (not through a download of the whole matrix)."""
+        if len(self.shape) != 2:
+            return np.diagonal(self.numpy())
+        m = min(self.shape)
+        out = np.empty(m, dtype=self.dtype)
+        if m:
+            isz = self.dtype.itemsize
+            self.ctx.call("smn_memcpy2d_d2h", out.ctypes.data_as(C.c_void_p), isz, self.ptr, (self.ld + 1) * isz, isz, m)
+        if self.scale != 1.0:
+            out *= self.dtype.type(self.scale)
+        if self.shift != 0.0:
+            out += self.dtype.type(self.shift)
+        return out
 
     def flatten(self):
         return self.numpy().flatten()

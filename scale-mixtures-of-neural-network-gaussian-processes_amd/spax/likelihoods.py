@@ -5,12 +5,19 @@ import math
 
 import numpy as np
 
-from .._lib import as_device
+from .._lib import DeviceArray, as_device
 from .base import ConstraintTrainVar, Module
 from .bijectors import positive
 from .utils import factor_stats, jitter, multivariate_normal_logpdf, multivariate_t_logpdf
 
 __all__ = ["Likelihood", "GaussianLikelihood", "StudentTLikelihood"]
+
+
+def _diag64(cov):
+    """diag(cov) in float64; a device matrix hands over its diagonal only (the marginal heads below read nothing else)."""
+    if isinstance(cov, DeviceArray):
+        return np.asarray(cov.diagonal(), dtype=np.float64)
+    return np.diagonal(np.asarray(cov, dtype=np.float64))
 
 
 def _norm_logpdf(x, mean, sigma):
@@ -42,7 +49,7 @@ class GaussianLikelihood(Likelihood):
 
     def logpdf(self, x, mean, cov, aux):
         """spax/likelihoods.py:30-33."""
-        sigma = np.sqrt(np.diagonal(np.asarray(cov, dtype=np.float64)))
+        sigma = np.sqrt(_diag64(cov))
         return _norm_logpdf(np.asarray(x, dtype=np.float64), np.asarray(mean, dtype=np.float64), sigma)
 
 
@@ -84,5 +91,5 @@ class StudentTLikelihood(Likelihood):
                 cov_data = as_device(np.asarray(cov_data, dtype=np.float64), getattr(cov_data, "ctx", None))
             quad, _, _ = factor_stats(y_data, (b / a) * cov_data + jitter(num_data))
         d = df + quad
-        sigma = np.sqrt(np.diagonal(d / cond_df * b / a * np.asarray(cov, dtype=np.float64)))
+        sigma = np.sqrt(d / cond_df * b / a * _diag64(cov))
         return _t_logpdf(np.asarray(x, dtype=np.float64), cond_df, np.asarray(mean, dtype=np.float64), sigma)

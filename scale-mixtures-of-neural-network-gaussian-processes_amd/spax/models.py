@@ -7,7 +7,7 @@ import ctypes as C
 import numpy as np
 
 from .. import _lib
-from .._lib import as_device
+from .._lib import DeviceArray, as_device
 from ..nt_kernels import KernelFn
 from .base import ConstraintTrainVar, Module
 from .bijectors import positive
@@ -140,7 +140,7 @@ class SPR(Module):
         log_prob = self.likelihood.logpdf(
             (y * self.y_std) + self.y_mean,
             (np.asarray(mean, dtype=np.float64).flatten() * self.y_std) + self.y_mean,
-            np.asarray(cov, dtype=np.float64) * self.y_std ** 2,
+            cov * self.y_std ** 2 if isinstance(cov, DeviceArray) else np.asarray(cov, dtype=np.float64) * self.y_std ** 2,
             aux,
         )
         ll = np.mean(log_prob)
