@@ -7,8 +7,8 @@
 // alpha and -K~^-1 come out of the SAME augmented factorisation the predictive head uses
 // (smn_predict with K_td = I, K_tt = 0: mean = alpha, "covariance" = -K~^-1), so the only new device
 // code is the contraction: one pass over the lower triangle of K0 = X X^T / d that carries
-// (K, dK/dw^2, dK/db^2) through the layer stack in forward mode (fp64 arithmetic whatever the storage
-// type) and accumulates  sum G dK/dw_std,  sum G dK/db_std,  sum G dK/dlast_w_std,  tr G.
+// (K, dK/dw^2, dK/db^2) through the layer stack in forward mode (in the arithmetic of the storage type,
+// sums in fp64) and accumulates  sum G dK/dw_std,  sum G dK/db_std,  sum G dK/dlast_w_std,  tr G.
 //
 // Forward-mode rules (SURVEY.md Appendix A.1/A.2 differentiated; q_i, q_j = variances entering the map):
 //   Dense:  A = w2 K + b2           dA/dw2 = K + w2 dK/dw2          dA/db2 = 1 + w2 dK/db2
@@ -57,11 +57,53 @@ __device__ __forceinline__ ActD act_d(double a, double qi, double qj) {
   return r;
 }
 
-// Diagonal of the same recursion: variance entering each activation and its derivatives.
-// tab[(s*3 + 0)*n + i] = q,  +1: dq/dw2,  +2: dq/db2.
-template <int NET, int ACT>
+// The same maps per ELEMENT, in the arithmetic R of the storage type (float for f32 matrices: the Gram entries and
+// -K~^-1 carry f32 rounding already, fp64 arithmetic on them recovers nothing; double for f64), division-free from per-row
+// tables and with the branch-free asin of the forward kernels (nngp_math.hpp) instead of libm's acos:
+//   ReLU: ra = 1/sqrt(q), rb = sqrt(q):   c = A ra_i ra_j,  pi - acos c = pi/2 + asin c,  sp = rb_i rb_j,
+//         phi_qi = sqrt(1-c^2) sp / (4 pi q_i) = sqrt(1-c^2)/(4 pi) * rb_j ra_i
+//   Erf:  ra = 1/sqrt(1+2q), rb = ra^2:   s = 2 A ra_i ra_j,  phi_A = (4/pi) ra_i ra_j / sqrt(1-s^2),
+//         phi_qi = -(2/pi) s rb_i / sqrt(1-s^2)
+template <typename R>
+struct ActR {
+  R o, dA, d1, d2;
+};
+
+template <int ACT, typename R>
+__device__ __forceinline__ ActR<R> act_r(R a, R rai, R rbi, R raj, R rbj) {
+  ActR<R> r;
+  if (ACT == ACT_RELU) {
+    const R c = nngp::clamp1(a * (rai * raj));
+    const R as = nngp::asin_abs(fabs(c), c * c);
+    const R s1 = nngp::fast_sqrt(fmax(fma(-c, c, R(1)), R(0)));
+    const R pm = R(kPiD / 2) + copysign(as, c);
+    const R sp = rbi * rbj;
+    r.o = sp * fma(pm, c, s1) * R(1.0 / (2.0 * kPiD));
+    r.dA = pm * R(1.0 / (2.0 * kPiD));
+    const R t = s1 * R(1.0 / (4.0 * kPiD));
+    r.d1 = t * (rbj * rai);
+    r.d2 = t * (rbi * raj);
+  } else {
+    const R uu = rai * raj;
+    const R sv = nngp::clamp1(R(2) * a * uu);
+    const R as = nngp::asin_abs(fabs(sv), sv * sv);
+    const R rden = nngp::fast_rsqrt(fmax(fma(-sv, sv, R(1)), sizeof(R) == 8 ? R(1e-300) : R(1e-30)));
+    r.o = R(2.0 / kPiD) * copysign(as, sv);
+    r.dA = R(4.0 / kPiD) * uu * rden;
+    const R t = R(-2.0 / kPiD) * sv * rden;
+    r.d1 = t * rbi;
+    r.d2 = t * rbj;
+  }
+  return r;
+}
+
+constexpr int kTabFields = 5;   // per activation layer and row: q, dq/dw2, dq/db2, ra, rb
+
+// Diagonal of the same recursion (fp64 arithmetic): variance entering each activation, its derivatives and the two
+// per-row factors of act_r.  tab[(s*5 + f)*n + i], f = 0: q, 1: dq/dw2, 2: dq/db2, 3: ra, 4: rb.
+template <int NET, int ACT, typename R>
 __global__ void grad_tables_kernel(const double* __restrict__ q0, int64_t n, int nsets, double w2, double b2,
-                                   double* __restrict__ tab) {
+                                   R* __restrict__ tab) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   double q = q0[i], dw = 0.0, db = 0.0;
@@ -77,9 +119,17 @@ __global__ void grad_tables_kernel(const double* __restrict__ q0, int64_t n, int
       db = 1.0 + w2 * db;
       q = qa;
     }
-    tab[(int64_t)(s * 3 + 0) * n + i] = q;
-    tab[(int64_t)(s * 3 + 1) * n + i] = dw;
-    tab[(int64_t)(s * 3 + 2) * n + i] = db;
+    R* t = tab + (int64_t)s * kTabFields * n + i;
+    t[0] = (R)q;
+    t[n] = (R)dw;
+    t[2 * n] = (R)db;
+    if (ACT == ACT_RELU) {
+      t[3 * n] = (R)(1.0 / sqrt(q));
+      t[4 * n] = (R)sqrt(q);
+    } else {
+      t[3 * n] = (R)(1.0 / sqrt(1.0 + 2.0 * q));
+      t[4 * n] = (R)(1.0 / (1.0 + 2.0 * q));
+    }
     const ActD r = act_d<ACT>(q, q, q);           // on the diagonal A = q_i = q_j
     const double dq = r.dA + r.d1 + r.d2;
     double o = r.o, ow = dq * dw, ob = dq * db;
@@ -96,11 +146,12 @@ __global__ void grad_tables_kernel(const double* __restrict__ q0, int64_t n, int
 
 template <typename T>
 struct GradArgs {
+  using R = T;                       // arithmetic of the per-element chain
   const T* k0; int64_t ldk0;
   const T* nkinv; int64_t ldki;      // -K~^-1
   const T* alpha;
   int64_t n;
-  const double* tab;                 // grad_tables_kernel output
+  const R* tab;                      // grad_tables_kernel output
   int nsets;
   double w2, b2, lw2, coef;
   double* partial;                   // [gridDim.x][4]
@@ -108,52 +159,75 @@ struct GradArgs {
 
 constexpr int GT = 64;               // tile edge of the contraction
 
+// One 64 x 64 tile of the lower triangle per workgroup; a thread owns one column and 16 rows (wave w: rows w, w+4, ...)
+// and carries their (K, dK/dw2, dK/db2) through the layers together: the column-side table entries are loaded once per
+// layer, the row-side ones are wave-uniform (scalar loads).  Products in R, the four sums in double.
 template <typename T, int NET, int ACT>
 __global__ void __launch_bounds__(256) grad_contract_kernel(GradArgs<T> a) {
+  using R = typename GradArgs<T>::R;
   int tr, tc;
   tri_decode(blockIdx.x, tr, tc);
   const int64_t row0 = (int64_t)tr * GT, col0 = (int64_t)tc * GT, n = a.n;
   const int tid = threadIdx.x;
   const int lc = tid % GT;
-  double acc[4] = {0.0, 0.0, 0.0, 0.0};   // sum G dK/dw2, sum G dK/db2, sum G K, tr G
-  const int64_t j = col0 + lc;
-  for (int lr = tid / GT; lr < GT; lr += 256 / GT) {
-    const int64_t i = row0 + lr;
-    if (i >= n || j >= n || j > i) continue;
-    double k = (double)a.k0[i * a.ldk0 + j], dw = 0.0, db = 0.0;
+  const int w = __builtin_amdgcn_readfirstlane(tid / GT);
+  constexpr int NR = GT / 4;
+  const int64_t j = col0 + lc, jc = j < n ? j : n - 1;
+  const R w2 = (R)a.w2, b2 = (R)a.b2;
+  R k[NR], dw[NR], db[NR];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    const int64_t i = row0 + w + 4 * r, ic = i < n ? i : n - 1;
+    k[r] = (R)a.k0[ic * a.ldk0 + jc];
+    dw[r] = R(0);
+    db[r] = R(0);
     if (NET == NET_RESNET) {
-      dw = k;
-      db = 1.0;
-      k = a.w2 * k + a.b2;
+      dw[r] = k[r];
+      db[r] = R(1);
+      k[r] = fma(w2, k[r], b2);
     }
-    for (int s = 0; s < a.nsets; ++s) {
+  }
+  for (int s = 0; s < a.nsets; ++s) {
+    const R* ts = a.tab + (int64_t)s * kTabFields * n;
+    const R cdw = ts[n + jc], cdb = ts[2 * n + jc], cra = ts[3 * n + jc], crb = ts[4 * n + jc];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const int64_t i = row0 + w + 4 * r, ic = i < n ? i : n - 1;   // wave-uniform
+      const R rq = ts[ic], rdw = ts[n + ic], rdb = ts[2 * n + ic], rra = ts[3 * n + ic], rrb = ts[4 * n + ic];
+      R kk = k[r], kw = dw[r], kb = db[r];
       if (NET == NET_MLP) {
-        const double ka = a.w2 * k + a.b2;
-        dw = k + a.w2 * dw;
-        db = 1.0 + a.w2 * db;
-        k = ka;
+        kw = fma(w2, kw, kk);
+        kb = fma(w2, kb, R(1));
+        kk = fma(w2, kk, b2);
       }
-      const double qi = a.tab[(int64_t)(s * 3 + 0) * n + i], qj = a.tab[(int64_t)(s * 3 + 0) * n + j];
-      if (i == j) k = qi;                         // exact diagonal
-      const ActD r = act_d<ACT>(k, qi, qj);
-      double o = r.o;
-      double ow = r.dA * dw + r.d1 * a.tab[(int64_t)(s * 3 + 1) * n + i] + r.d2 * a.tab[(int64_t)(s * 3 + 1) * n + j];
-      double ob = r.dA * db + r.d1 * a.tab[(int64_t)(s * 3 + 2) * n + i] + r.d2 * a.tab[(int64_t)(s * 3 + 2) * n + j];
+      if (i == j) kk = rq;                        // exact diagonal
+      const ActR<R> q = act_r<ACT, R>(kk, rra, rrb, cra, crb);
+      R o = q.o;
+      R ow = fma(q.dA, kw, fma(q.d1, rdw, q.d2 * cdw));
+      R ob = fma(q.dA, kb, fma(q.d1, rdb, q.d2 * cdb));
       if (NET == NET_RESNET && s != a.nsets - 1) {
-        const double ka = a.w2 * o + a.b2;
-        const double kw = o + a.w2 * ow, kb = 1.0 + a.w2 * ob;
-        o = k + ka;
-        ow = dw + kw;
-        ob = db + kb;
+        const R ka = fma(w2, o, b2);
+        const R aw = fma(w2, ow, o), ab = fma(w2, ob, R(1));
+        o = kk + ka;
+        ow = kw + aw;
+        ob = kb + ab;
       }
-      k = o; dw = ow; db = ob;
+      k[r] = o; dw[r] = ow; db[r] = ob;
     }
-    const double g = a.coef * (double)a.alpha[i] * (double)a.alpha[j] + (double)a.nkinv[i * a.ldki + j];
-    const double m = (i == j) ? 1.0 : 2.0;        // the upper triangle is the mirror image
-    acc[0] += m * g * a.lw2 * dw;
-    acc[1] += m * g * a.lw2 * db;
-    acc[2] += m * g * a.lw2 * k;
-    if (i == j) acc[3] += g;
+  }
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};   // sum G dK/dw2, sum G dK/db2, sum G K, tr G
+  const R aj = (R)a.alpha[jc], coef = (R)a.coef, lw2 = (R)a.lw2;
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    const int64_t i = row0 + w + 4 * r, ic = i < n ? i : n - 1;
+    const bool valid = i < n && j < n && j <= i;
+    const R g = fma(coef * (R)a.alpha[ic], aj, (R)a.nkinv[ic * a.ldki + jc]);
+    const R m = !valid ? R(0) : (i == j ? R(1) : R(2));   // the upper triangle is the mirror image
+    const R gm = m * g * lw2;
+    acc[0] += (double)(gm * dw[r]);
+    acc[1] += (double)(gm * db[r]);
+    acc[2] += (double)(gm * k[r]);
+    if (valid && i == j) acc[3] += (double)g;
   }
   __shared__ double red[4][4];
 #pragma unroll
@@ -195,8 +269,8 @@ __global__ void cast_q_kernel(const T* __restrict__ s, double* __restrict__ d, i
 
 template <typename T, int NET, int ACT>
 int grad_terms_na(smn_ctx* ctx, const GradArgs<T>& a, const double* q64, int64_t ntiles, double* out_d) {
-  hipLaunchKernelGGL((grad_tables_kernel<NET, ACT>), dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0, ctx->stream,
-                     q64, a.n, a.nsets, a.w2, a.b2, const_cast<double*>(a.tab));
+  hipLaunchKernelGGL((grad_tables_kernel<NET, ACT, T>), dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0, ctx->stream,
+                     q64, a.n, a.nsets, a.w2, a.b2, const_cast<T*>(a.tab));
   SMN_CHECK_LAUNCH(ctx);
   {
     ProfScope ps(ctx, PROF_MISC, ctx->stream);
@@ -216,11 +290,12 @@ int grad_terms_t(smn_ctx* ctx, int net, int act, int num_hiddens, double w_std, 
   if (nsets > kMaxSets) return smn_fail(ctx, SMN_ENOTSUP, "num_hiddens too large (max %d activation layers)", kMaxSets);
   const int64_t t = (n + GT - 1) / GT, ntiles = t * (t + 1) / 2;
   void* wsv = nullptr;
-  const size_t nd = (size_t)n * (1 + 3 * (size_t)(nsets > 0 ? nsets : 1)) + (size_t)ntiles * 4 + 4;
+  const size_t ntab = (size_t)n * kTabFields * (size_t)(nsets > 0 ? nsets : 1);   // T-typed; sized as doubles
+  const size_t nd = (size_t)n + ntab + (size_t)ntiles * 4 + 4;
   SMN_TRY(smn_workspace(ctx, 4, sizeof(double) * nd, &wsv));
   double* q64 = static_cast<double*>(wsv);
-  double* tab = q64 + n;
-  double* partial = tab + (size_t)n * 3 * (size_t)(nsets > 0 ? nsets : 1);
+  double* tabd = q64 + n;
+  double* partial = tabd + ntab;
   double* out_d = partial + (size_t)ntiles * 4;
   hipLaunchKernelGGL(cast_q_kernel<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
                      static_cast<const T*>(q), q64, n);
@@ -229,7 +304,7 @@ int grad_terms_t(smn_ctx* ctx, int net, int act, int num_hiddens, double w_std, 
   a.k0 = static_cast<const T*>(k0); a.ldk0 = ldk0;
   a.nkinv = static_cast<const T*>(nkinv); a.ldki = ldki;
   a.alpha = static_cast<const T*>(alpha);
-  a.n = n; a.tab = tab; a.nsets = nsets;
+  a.n = n; a.tab = reinterpret_cast<const T*>(tabd); a.nsets = nsets;
   a.w2 = w_std * w_std; a.b2 = b_std * b_std; a.lw2 = last_w_std * last_w_std; a.coef = coef;
   a.partial = partial;
   int rc;

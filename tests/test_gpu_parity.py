@@ -1079,6 +1079,44 @@ def test_analytic_gradient_at_sizes_that_skip_identity_tiles(dtype, n):
         assert abs(got - ref[k]) < tol * max(scale, abs(ref[k])), (k, got, ref[k])
 
 
+def test_gradient_factorisation_launches_only_the_live_tiles_of_the_identity_block():
+    """[[K~, .], [I, 0]] factored as a dense 2N x 2N matrix would execute ~2.3 N^3 update flops; with the structural zeros
+    of the identity rows left out of every launch it is ~N^3 (chol N^3/3 + L^-T N^3/3 + L^-T L^-1 N^3/3).  The library counts
+    the flops of the tiles it launches (smn_profile_flops), so this pins the launch shapes, not a timing."""
+    from smnngp import nt_kernels, _lib as L
+    from smnngp.spax.kernels import NNGPKernel
+    from smnngp.spax.likelihoods import GaussianLikelihood
+    from smnngp.spax.models import SPR
+    n, d = 4096, 64
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((n, d)).astype(np.float32); y = rng.standard_normal(n).astype(np.float32)
+    kernel = NNGPKernel(lambda w, b, l: nt_kernels.get_mlp_kernel(2, 1, act="relu", w_std=w, b_std=b, last_w_std=l), 1.0, 0.3, 1.0)
+    model = SPR(kernel, GaussianLikelihood(), x, y, 0.0, 1.0, eps=1e-2)
+    ctx = model.x_data.ctx
+    model.loss_and_grad()
+    ctx.call("smn_profile_enable", 0)          # resets the counters
+    loss, grads = model.loss_and_grad()
+    fl = 0.0
+    for cat in (4, 5):
+        v = C.c_double()
+        ctx.call("smn_profile_flops", cat, C.byref(v))
+        fl += v.value
+    assert np.isfinite(loss) and all(np.isfinite(g) for g in grads.values())
+    assert 0.9 * n ** 3 < fl < 1.45 * n ** 3, fl / n ** 3      # whole 128 x 128 tiles: a little above N^3 at this size
+
+
+def test_device_matrix_hands_over_its_diagonal_without_a_full_download():
+    from smnngp import _lib as L
+    ctx = L.default_context()
+    rng = np.random.default_rng(2)
+    for dtype, shape in ((np.float32, (37, 37)), (np.float64, (20, 33)), (np.float32, (1, 1))):
+        a = rng.standard_normal(shape).astype(dtype)
+        d = ctx.to_device(a)
+        assert np.array_equal(d.diagonal(), np.diagonal(a))
+        v = d * 2.5
+        np.testing.assert_allclose(v.diagonal(), 2.5 * np.diagonal(a), rtol=1e-6)
+
+
 def test_analytic_train_step_descends_and_agrees_with_fd_step():
     """regression/train.py:61-67 with the analytic gradient: same first Adam update as finite differences."""
     from smnngp import nt_kernels, train
