@@ -92,8 +92,7 @@ def find_grid(x_train, y_train, x_test, y_test, y_mean=0.0, y_std=1.0, *, networ
             if info.value:
                 continue
             mean_ = mean_d.numpy().astype(np.float64).ravel() * y_std + y_mean
-            cov = cov_d.numpy().astype(np.float64)
-            std_diag = np.sqrt(np.diag(cov))
+            std_diag = np.sqrt(cov_d.diagonal().astype(np.float64))   # only the marginal variances are used (find.py:50-55)
             gnll[i, j, k] = -np.mean(_norm_logpdf(y_, mean_, std_diag * y_std))             # find.py:50-55,145
             # find.py:151-159 — y^T (K + eps I)^-1 y and log det, absolute eps, training block of kj
             c.call("smn_lml", code, kj.ptr, n, ldm, yd.ptr, float(eps), 0.0, 1.0, None, C.byref(quad),
