@@ -163,6 +163,10 @@ int smn_cholesky(smn_ctx* ctx, int dtype, void* a_d, int64_t n_total, int64_t n_
  * (lax.linalg.triangular_solve, spax/utils.py:180.) */
 int smn_trsm(smn_ctx* ctx, int dtype, const void* l_d, int64_t n, int64_t ldl,
              void* b_d, int64_t nrhs, int64_t ldb, int trans);
+/* dst_d[c, r] = src_d[r, c] for r < rows, c < cols (row-major, leading dimensions in elements; no overlap).  The NTK
+ * posterior of gradient_descent_mse_ensemble (sample.ipynb:194-195) needs Theta~^-1 Theta_dt as a left operand. */
+int smn_transpose(smn_ctx* ctx, int dtype, void* dst_d, int64_t ldd, const void* src_d, int64_t lds, int64_t rows,
+                  int64_t cols);
 
 /* ---- likelihood heads (host scalars out) ----
  * smn_lml: log-marginal likelihood of y_d [n] under cov = K + eps I, K given as k_d [n,n] lower

@@ -72,6 +72,7 @@ PROTOTYPES = {
     "smn_kernel_conv_resnet": [_vp, _i, _i, _i, _d, _d, _d, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _i, _vp, _i64],
     "smn_cholesky": [_vp, _i, _vp, _i64, _i64, _i64, _i64, _d, _d, _pi, _pd],
     "smn_trsm": [_vp, _i, _vp, _i64, _i64, _vp, _i64, _i64, _i],
+    "smn_transpose": [_vp, _i, _vp, _i64, _vp, _i64, _i64, _i64],
     "smn_lml": [_vp, _i, _vp, _i64, _i64, _vp, _d, _d, _d, _pd, _pd, _pd, _pi],
     "smn_predict": [_vp, _i, _vp, _i64, _i64, _i64, _vp, _i64, _d, _d, _vp, _vp, _i64, _pd, _pd, _pi],
     "smn_spr_loss": [_vp, _i, _i, _i, _i, _d, _d, _d, _vp, _i64, _i64, _i64, _vp, _d, _d, _d, _pd, _pd, _pd, _pi],

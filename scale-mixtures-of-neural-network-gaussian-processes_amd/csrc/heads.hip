@@ -173,6 +173,15 @@ extern "C" int smn_trsm(smn_ctx* ctx, int dtype, const void* l_d, int64_t n, int
   return SMN_OK;
 }
 
+extern "C" int smn_transpose(smn_ctx* ctx, int dtype, void* dst_d, int64_t ldd, const void* src_d, int64_t lds, int64_t rows,
+                             int64_t cols) {
+  if (!ctx || !dst_d || !src_d) return SMN_EINVAL;
+  SMN_ENTER(ctx);
+  if (dtype != SMN_F32 && dtype != SMN_F64) return smn_fail(ctx, SMN_EINVAL, "bad dtype");
+  if (rows < 0 || cols < 0 || lds < cols || ldd < rows) return smn_fail(ctx, SMN_EINVAL, "smn_transpose: bad sizes");
+  return transpose_matrix(ctx, dtype, dst_d, ldd, src_d, lds, rows, cols);
+}
+
 extern "C" int smn_lml(smn_ctx* ctx, int dtype, void* k_d, int64_t n, int64_t ldk, const void* y_d, double eps_abs,
                        double df, double scale, double* logpdf_h, double* quad_h, double* logdet_h, int* info_h) {
   if (!ctx || !k_d || !y_d) return SMN_EINVAL;

@@ -69,10 +69,11 @@ def gradient_descent_mse_ensemble(kernel_fn, x_train, y_train, diag_reg=0.0, dia
 
     def _predict_ntk(x_test, compute_cov):
         """get='ntk' (the reference uses it in sample.ipynb only):
-            mean = Theta_td Theta~^-1 y,   a = Theta~^-1 Theta_dt,
+            mean = Theta_td Theta~^-1 y = a^T y,   a = Theta~^-1 Theta_dt,
             cov  = K_tt + a^T K_dd a - (a^T K_dt + K_td a),      Theta~ = Theta_dd + diag_reg tr(Theta_dd)/N I.
-        Composed from the public pieces: one joint (NNGP, NTK) kernel build, smn_cholesky of Theta_dd, two smn_trsm
-        (= cho_solve) on [Theta_dt | y], one device GEMM K_dd a (smn_gram is a general A B^T / d), T x T host algebra."""
+        Composed from the public pieces, on the device: one joint (NNGP, NTK) kernel build, smn_cholesky of Theta_dd in place,
+        two smn_trsm (= cho_solve) on the Theta_dt block where it lies, one transpose, four products through smn_gram
+        (a general A B^T / d); only the T x T sum is host arithmetic."""
         xt = x if x_test is None else as_device(x_test, ctx, dtype=x.dtype)
         tt = xt.shape[0]
         dt = x.dtype
@@ -81,30 +82,40 @@ def gradient_descent_mse_ensemble(kernel_fn, x_train, y_train, diag_reg=0.0, dia
         kj, tj = as_device(both[0], ctx, dtype=dt), as_device(both[1], ctx, dtype=dt)
         m = n + tt
         es = dt.itemsize
-        kj_h_td = np.empty((tt, m), dt); tj_h_td = np.empty((tt, m), dt)          # rows n.. of both joint kernels
-        ctx.call("smn_memcpy_d2h", kj_h_td.ctypes.data_as(C.c_void_p), C.c_void_p(kj.ptr.value + n * m * es), tt * m * es)
-        ctx.call("smn_memcpy_d2h", tj_h_td.ctypes.data_as(C.c_void_p), C.c_void_p(tj.ptr.value + n * m * es), tt * m * es)
-        k_td, k_tt, t_td = kj_h_td[:, :n].astype(np.float64), kj_h_td[:, n:].astype(np.float64), tj_h_td[:, :n]
+        code = x.dcode
+
+        def at(arr, row, col):                                                       # address of arr[row, col], ld = m
+            return C.c_void_p(arr.ptr.value + (row * m + col) * es)
+
         rel, ab = (0.0, float(diag_reg)) if diag_reg_absolute_scale else (float(diag_reg), 0.0)
         info, logdet = C.c_int(), C.c_double()
-        ctx.call("smn_cholesky", x.dcode, tj.ptr, n, n, m, n, ab, rel, C.byref(info), C.byref(logdet))   # Theta_dd -> L
+        ctx.call("smn_cholesky", code, tj.ptr, n, n, m, n, ab, rel, C.byref(info), C.byref(logdet))   # Theta_dd -> L
         if info.value != 0:
             nanm = np.full((tt, c), np.nan, dtype=dt)
             return (nanm, np.full((tt, tt), np.nan, dtype=dt)) if compute_cov else nanm
-        rhs = ctx.to_device(np.ascontiguousarray(np.concatenate([t_td.T, y.numpy().reshape(n, c)], axis=1), dtype=dt))
-        for trans in (0, 1):
-            ctx.call("smn_trsm", x.dcode, tj.ptr, n, m, rhs.ptr, tt + c, tt + c, trans)
-        sol = rhs.numpy().astype(np.float64)                                         # [a | Theta~^-1 y]
-        a, v = sol[:, :tt], sol[:, tt:]
-        mean = t_td.astype(np.float64) @ v
+        for trans in (0, 1):                                                         # a, in place of Theta_dt
+            ctx.call("smn_trsm", code, tj.ptr, n, m, at(tj, 0, n), tt, m, trans)
+        a_t = ctx.empty((tt, n), dt)
+        ctx.call("smn_transpose", code, a_t.ptr, n, at(tj, 0, n), m, n, tt)
+        if c == 1:
+            y_t = y                                                                  # [N, 1] is [1, N]
+        else:
+            y_t = ctx.empty((c, n), dt)
+            ctx.call("smn_transpose", code, y_t.ptr, n, y.ptr, c, n, c)
+        mean_d = ctx.empty((tt, c), dt)
+        ctx.call("smn_gram", code, a_t.ptr, tt, n, y_t.ptr, c, n, n, mean_d.ptr, c, None, None)      # a^T y / N
+        mean = mean_d.numpy().astype(np.float64) * n
         if not compute_cov:
             return mean.astype(dt)
-        at = ctx.to_device(np.ascontiguousarray(a.T, dtype=dt))                      # [T, N]
-        ka = ctx.empty((n, tt), dt)
-        ctx.call("smn_gram", x.dcode, kj.ptr, n, m, at.ptr, tt, n, n, ka.ptr, tt, None, None)   # K_dd a / n
-        kda = ka.numpy().astype(np.float64) * n
-        cross = k_td @ a
-        cov = k_tt + a.T @ kda - (cross.T + cross)
+        ka_t = ctx.empty((tt, n), dt)
+        ctx.call("smn_gram", code, a_t.ptr, tt, n, kj.ptr, n, m, n, ka_t.ptr, n, None, None)         # a^T K_dd / N
+        quad_d, cross_d = ctx.empty((tt, tt), dt), ctx.empty((tt, tt), dt)
+        ctx.call("smn_gram", code, a_t.ptr, tt, n, ka_t.ptr, tt, n, n, quad_d.ptr, tt, None, None)    # a^T K_dd a / N^2
+        ctx.call("smn_gram", code, at(kj, n, 0), tt, m, a_t.ptr, tt, n, n, cross_d.ptr, tt, None, None)   # K_td a / N
+        k_tt = np.empty((tt, tt), dt)
+        ctx.call("smn_memcpy2d_d2h", k_tt.ctypes.data_as(C.c_void_p), tt * es, at(kj, n, n), m * es, tt * es, tt)
+        cross = cross_d.numpy().astype(np.float64) * n
+        cov = k_tt.astype(np.float64) + quad_d.numpy().astype(np.float64) * (float(n) * n) - (cross.T + cross)
         return mean.astype(dt), cov.astype(dt)
 
     return predict_fn
