@@ -22,6 +22,7 @@ import argparse
 import ctypes as C
 import json
 import os
+import shutil
 import subprocess
 import sys
 import tempfile
@@ -114,12 +115,7 @@ def launch_ranks(args):
                     q.terminate()
         if alive:
             time.sleep(0.05)
-    try:
-        for f in os.listdir(tmp):
-            os.unlink(os.path.join(tmp, f))
-        os.rmdir(tmp)
-    except OSError:
-        pass
+    shutil.rmtree(tmp, ignore_errors=True)
     sys.exit(rc)
 
 
@@ -173,6 +169,62 @@ class RankSync:
 
     def max(self, value):
         return max(self.gather(value))
+
+
+class FileSync:
+    """The same three calls through files in a directory every rank of the node sees: the fall-back when the RCCL
+    communicator cannot be brought up (the step then runs as independent replicas; there is nothing to exchange)."""
+
+    def __init__(self, directory, world, rank):
+        self.dir, self.world, self.rank, self.k = directory, world, rank, 0
+
+    def gather(self, value, timeout_s=600.0):
+        self.k += 1
+        mine = os.path.join(self.dir, "g%d_%d" % (self.k, self.rank))
+        with open(mine + ".tmp", "w") as f:
+            f.write(repr(float(value)))
+        os.replace(mine + ".tmp", mine)
+        out, t0 = [], time.time()
+        for r in range(self.world):
+            path = os.path.join(self.dir, "g%d_%d" % (self.k, r))
+            while True:
+                try:
+                    with open(path) as f:
+                        out.append(float(f.read()))
+                    break
+                except (FileNotFoundError, ValueError):
+                    if time.time() - t0 > timeout_s:
+                        raise RuntimeError("rank %d: rank %d never reached step %d of the file rendezvous" % (self.rank, r, self.k))
+                    time.sleep(0.0005)
+        return out
+
+    def barrier(self):
+        self.gather(0.0)
+
+    def max(self, value):
+        return max(self.gather(value))
+
+
+def agree_on_communicator(path, world, rank, ok, timeout_s=180.0):
+    """Every rank publishes whether its smn_comm_init succeeded; all of them read all of them.  Returns (all_ok, directory)."""
+    d = path + ".ranks"
+    os.makedirs(d, exist_ok=True)
+    mine = os.path.join(d, "init_%d" % rank)
+    with open(mine + ".tmp", "w") as f:
+        f.write("1" if ok else "0")
+    os.replace(mine + ".tmp", mine)
+    t0, flags = time.time(), []
+    for r in range(world):
+        while True:
+            try:
+                with open(os.path.join(d, "init_%d" % r)) as f:
+                    flags.append(f.read().strip() == "1")
+                break
+            except FileNotFoundError:
+                if time.time() - t0 > timeout_s:
+                    raise RuntimeError("rank %d: rank %d did not report its communicator within %.0f s" % (rank, r, timeout_s))
+                time.sleep(0.005)
+    return all(flags), d
 
 
 # ----------------------------------------------------------------------------- helpers
@@ -517,25 +569,45 @@ def main():
     eps = args.eps if args.eps is not None else (1e-3 if args.dtype == "f32" else 1e-6)
     act = L.ACT[args.act]
     n, d, nl = args.n, args.d, args.layers
-    ctx = L.Context(local_rank)
+    # SMN_BENCH_SHARE_GPU=1 (rehearsal on a one-GPU box only): every rank on device 0 -- RCCL refuses such a communicator,
+    # which exercises the replica fall-back below
+    ctx = L.Context(0 if os.environ.get("SMN_BENCH_SHARE_GPU") == "1" else local_rank)
 
     sharded = world > 1 or args.sharded_path
+    comm_fallback = None
     if world > 1:
         # under an external launcher the file name carries the launcher's own run id where it exports one, so that two
         # runs can never meet in one file
         path = args.rendezvous_file or os.path.join(
             tempfile.gettempdir(), "smnngp_uid_%s_%s_%d" % (os.environ.get("MASTER_PORT", "0"),
                                                             os.environ.get("TORCHELASTIC_RUN_ID", "run"), os.getppid()))
-        uid = exchange_rccl_id(L, path, rank)
-        ctx.call("smn_comm_init", world, rank, uid)
-    elif args.sharded_path:                        # one-rank communicator: the P>1 code path on a one-GPU box
-        uid = C.create_string_buffer(128)
-        assert L._lib.smn_comm_unique_id(uid) == 0, "RCCL unavailable"
-        ctx.call("smn_comm_init", 1, 0, uid)
-    sync = RankSync(ctx, world, rank)
-    if world > 1 and not args.rendezvous_file:
-        sync.barrier()                             # every rank has read the id: rank 0 removes the file
-        if rank == 0:
+        err = None
+        try:
+            uid = exchange_rccl_id(L, path, rank)
+            ctx.call("smn_comm_init", world, rank, uid)
+        except Exception as e:   # noqa: BLE001  (no RCCL, no peer access, ...): agree with the other ranks on what to do
+            err = "%s: %s" % (type(e).__name__, e)
+        all_ok, rank_dir = agree_on_communicator(path, world, rank, err is None)
+        if all_ok:
+            sync = RankSync(ctx, world, rank)
+        else:
+            # No exchange is possible: every rank runs the whole single-GPU step (replicas), timed with the same barrier
+            # and max over ranks through files, and the line says so -- a line beats a dead launcher.
+            if err is None:
+                ctx.call("smn_comm_destroy")
+            comm_fallback = err or "another rank could not join the RCCL communicator"
+            sys.stderr.write("bench.py rank %d: no communicator (%s): running %d independent replicas\n" % (rank, comm_fallback, world))
+            sharded = False
+            sync = FileSync(rank_dir, world, rank)
+    else:
+        if args.sharded_path:                      # one-rank communicator: the P>1 code path on a one-GPU box
+            uid = C.create_string_buffer(128)
+            assert L._lib.smn_comm_unique_id(uid) == 0, "RCCL unavailable"
+            ctx.call("smn_comm_init", 1, 0, uid)
+        sync = RankSync(ctx, world, rank)
+    if world > 1:
+        sync.barrier()                             # every rank has read the id: rank 0 removes the rendezvous files
+        if rank == 0 and not args.rendezvous_file:
             try:
                 os.unlink(path)
             except OSError:
@@ -709,7 +781,7 @@ def main():
                                    % (args.config.upper(), n, d, nl, args.act),
                        "N": n, "d": d, "layers": nl, "act": args.act, "w_std": 1.0, "b_std": 1e-8, "last_w_std": 1.0,
                        "eps_abs": eps, "flops_counted": flops_counted,
-                       "parallelism": "single GPU" if not sharded else
+                       "parallelism": ("single GPU" if world == 1 else "%d independent replicas (no RCCL communicator: %s)" % (world, comm_fallback)) if not sharded else
                        "paired lower-block row shards x%d, exchange in %d pieces pipelined behind the build (RCCL all-gather per piece), replicated Cholesky" % (world, parts)},
             "executed_tflops": executed / (ms_per_step * 1e-3) / 1e12,
             "executed_note": "MFMA flops actually issued per step (lower-triangle Gram tiles + whole update tiles; rank 0's share of the build when sharded) / step time; `value` counts 2N^2 d + N^3/3",

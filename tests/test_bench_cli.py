@@ -107,3 +107,29 @@ def test_launcher_ends_the_other_ranks_when_one_fails(tmp_path):
     t0 = time.time()
     r = subprocess.run([sys.executable, str(stub), "--gpus", "2"], capture_output=True, text=True, timeout=120, env=env)
     assert r.returncode == 7 and time.time() - t0 < 60
+
+
+def test_ranks_agree_on_a_failed_communicator_and_fall_back_to_the_file_rendezvous(tmp_path):
+    """If smn_comm_init fails on ANY rank (no RCCL, no peer access), every rank must learn it and run as a replica, with
+    the barrier and the max over ranks going through files: two processes, rank 1 reports a failed communicator."""
+    code = "\n".join([
+        "import sys, json", "sys.path.insert(0, %r)" % ROOT, "sys.argv = ['bench.py']", "import bench",
+        "rank = int(sys.argv[1]) if len(sys.argv) > 1 else 0",
+    ])
+    worker = tmp_path / "w.py"
+    worker.write_text("\n".join([
+        "import sys, json", "sys.path.insert(0, %r)" % ROOT, "rank = int(sys.argv[1]); sys.argv = ['bench.py']", "import bench",
+        "ok, d = bench.agree_on_communicator(%r, 2, rank, ok=(rank == 0), timeout_s=60)" % str(tmp_path / "rdv"),
+        "s = bench.FileSync(d, 2, rank)",
+        "s.barrier()",
+        "m = s.max(10.0 + rank)",
+        "g = s.gather(float(rank))",
+        "print(json.dumps(dict(ok=ok, max=m, gather=g)))"]))
+    del code
+    procs = [subprocess.Popen([sys.executable, str(worker), str(r)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for r in range(2)]
+    outs = [p.communicate(timeout=120) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1] for o in outs]
+    for o in outs:
+        got = json.loads(o[0].strip().splitlines()[-1])
+        assert got == {"ok": False, "max": 11.0, "gather": [0.0, 1.0]}
