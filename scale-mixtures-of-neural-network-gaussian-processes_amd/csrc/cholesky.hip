@@ -35,7 +35,7 @@
 // every setting; and the whole factorisation as ONE persistent launch with tile-granular dependencies (tasks POTRF /
 // TRSM / UPDATE, release / acquire hand-offs between workgroups): correct, 17.2 ms against 16.1 ms at N = 16384, because
 // its critical path -- POTRF + inverse, TRSM tile, diagonal update, three hand-offs per column -- is twice as long as the
-// fused panel's.  profiles/r02_notes.md, scratch/r02/potrf_trsm_experiment/, scratch/r02/dataflow_experiment/.)
+// fused panel's.  profiles/r02_notes.md; their sources are in the git history of round 2.)
 //   trail_kernel   persistent form of the near update (one stream of K-steps per workgroup).
 // Rows [id0, id1) may be declared an identity block (analytic gradients: cholesky_padded's hint): panel and update
 // workgroups whose rows are still structurally zero in the columns at hand leave at once.
