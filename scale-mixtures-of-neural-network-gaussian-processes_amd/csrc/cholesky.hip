@@ -485,18 +485,28 @@ __global__ void __launch_bounds__(2 * panel_threads(XRV)) panelr_kernel(T* __res
   // Block c's columns are final once its leaf is done: they leave for global memory (the appended rows' entries of L^-T
   // products in place, the factored diagonal block to the side buffer) in the chunk layout -- VPC lanes per row -- by
   // `nthr` threads that have nothing else to do (the helper waves beside the next leaf; everybody after the last one).
-  auto store_out = [&](int c, int t0, int nthr) {
-    for (int idx = t0; idx < ROWS * VPC; idx += nthr) {
-      const int r = idx / VPC, v = idx % VPC;
-      if (r < c * CB) continue;
-      T* dst = nullptr;
-      if (r < PB) {
-        if (blockIdx.x == 0 && ldiag_out) dst = ldiag_out + (int64_t)r * PB;
-      } else if (r - PB < nx) {
-        dst = a + (rb + (r - PB)) * lda + j0;
+  auto store_out = [&](int c, int t0, auto nthrc) {
+    // every LDS read first, then every store (a read -> store loop pays one LDS round trip per vector: 1.2 us per block
+    // in f64, more than the leaf it is meant to hide behind)
+    constexpr int NTHR = decltype(nthrc)::value, IT = (ROWS * VPC + NTHR - 1) / NTHR;
+    vec_t buf[IT];
+    T* dst[IT];
+#pragma unroll
+    for (int u = 0; u < IT; ++u) {
+      const int idx = u * NTHR + t0, r = idx / VPC, v = idx % VPC;
+      dst[u] = nullptr;
+      if (idx < ROWS * VPC && r >= c * CB) {
+        if (r < PB) {
+          if (blockIdx.x == 0 && ldiag_out) dst[u] = ldiag_out + (int64_t)r * PB + c * CB + v * VEC;
+        } else if (r - PB < nx) {
+          dst[u] = a + (rb + (r - PB)) * lda + j0 + c * CB + v * VEC;
+        }
       }
-      if (dst) *reinterpret_cast<vec_t*>(dst + c * CB + v * VEC) = *reinterpret_cast<const vec_t*>(&S[r * LD + c * CB + v * VEC]);
+      if (dst[u]) buf[u] = *reinterpret_cast<const vec_t*>(&S[r * LD + c * CB + v * VEC]);
     }
+#pragma unroll
+    for (int u = 0; u < IT; ++u)
+      if (dst[u]) *reinterpret_cast<vec_t*>(dst[u]) = buf[u];
   };
 #ifdef SMN_PANEL_TIMING   // timeline of wg 0 of the first panel: ticks (100 MHz) since kernel start, per block, per wave, 6 marks
   int* const tlog = reinterpret_cast<int*>(S + ROWS * LD + NW * CB * kLeafTileLd(sizeof(T)));
@@ -539,7 +549,8 @@ __global__ void __launch_bounds__(2 * panel_threads(XRV)) panelr_kernel(T* __res
         chunk_store(cbuf[SLOT], b + 1);
         if (b + 4 < NB) chunk_load(cbuf[SLOT], b + 4);
       }
-      if (b > 0) store_out(b - 1, hid, NTV);        // beside leaf b
+      TL(b, 1);
+      if (b > 0) store_out(b - 1, hid, std::integral_constant<int, NTV>{});        // beside leaf b
       TL(b, 2);
       if (b + 1 >= NB) return;
       __syncthreads();                              // A: block b is solved in every row
@@ -648,7 +659,7 @@ __global__ void __launch_bounds__(2 * panel_threads(XRV)) panelr_kernel(T* __res
                tlog[(w * NB + b) * 6 + 4], tlog[(w * NB + b) * 6 + 5]);
 #endif
 #undef TL
-  store_out(NB - 1, tid, 2 * NTV);
+  store_out(NB - 1, tid, std::integral_constant<int, 2 * NTV>{});
   if (blockIdx.x == 0 && tid < 64) {
     // logdet += 2 sum_j log L_jj; info = first pivot that is not a positive number (d <= 0 came out of the leaf as NaN)
     const T d0 = S[tid * LD + tid], d1 = S[(tid + 64) * LD + tid + 64];
