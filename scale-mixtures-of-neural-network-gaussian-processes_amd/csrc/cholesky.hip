@@ -420,9 +420,12 @@ __global__ void __launch_bounds__(2 * panel_threads(XRV)) panelr_kernel(T* __res
   auto update = [&](int cn, int first) {
     int rt[2];
     bool on[2];
+    // Second tiles go to the waves that are alone on their SIMD first (waves w and w + 4 share one: of six waves, 2 and 3
+    // are alone), so that no SIMD carries three tiles while another carries one.
+    const int slot2 = 2 * NW == 6 ? (wave == 2 ? 0 : wave == 3 ? 1 : wave < 2 ? wave + 2 : wave) : wave;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int t = first + wave + j * 2 * NW;
+      const int t = first + (j == 0 ? wave : 2 * NW + slot2);
       on[j] = t < RT;
       rt[j] = (on[j] ? t : first + wave) * M::TM;
     }
