@@ -1246,32 +1246,42 @@ int cholesky_padded(smn_ctx* ctx, int dtype, void* a, int64_t n_total, int64_t n
 int solve_rows_padded(smn_ctx* ctx, int dtype, void* a, int64_t n_total, int64_t n_factor, int64_t lda) {
   if (n_total % kTile || n_factor % kTile) return smn_fail(ctx, SMN_EINVAL, "solve_rows_padded: padding");
   hipStream_t st = ctx->stream;
-  for (int64_t js = 0; js < n_factor; js += PB) {
-    if (dtype == SMN_F64) {
-      SMN_TRY(set_lds_attrs<double>(ctx));
-      // appended rows only: C = a[n_factor:, js:js+128] -= a[n_factor:, 0:js] * a[js:js+128, 0:js]^T
-      SMN_TRY(launch_update<double>(ctx, st, static_cast<double*>(a), lda, n_factor, js, 0, (int)js,
-                                    (n_total - n_factor) / kTile, 1, 0));
-    } else {
-      SMN_TRY(set_lds_attrs<float>(ctx));
-      SMN_TRY(launch_update<float>(ctx, st, static_cast<float*>(a), lda, n_factor, js, 0, (int)js,
-                                   (n_total - n_factor) / kTile, 1, 0));
+  const int64_t tm = (n_total - n_factor) / kTile;
+  // Two-level like the factorisation: left-looking inside a super-panel of S columns (the update of a 128-column block
+  // reaches back to the super-panel's first column only), and when the super-panel is solved every later column of the
+  // appended rows takes its contribution at once (K = S, tm x (columns left / 128) tiles: a launch that fills the chip,
+  // where the purely left-looking sweep issued n_factor / 128 launches of tm tiles with K up to n_factor).
+  int64_t S = ctx->super_panel / PB * PB;
+  if (S < PB) S = PB;
+  auto upd = [&](int64_t c0, int64_t k0, int64_t K, int64_t tiles_n) -> int {
+    const int tag = K >= 256 ? 1 : 0;   // the pipelined K loop from K = 256 on (profile category: trailing update)
+    if (dtype == SMN_F64) return launch_update<double>(ctx, st, static_cast<double*>(a), lda, n_factor, c0, k0, K, tm, tiles_n, 0, tag);
+    return launch_update<float>(ctx, st, static_cast<float*>(a), lda, n_factor, c0, k0, K, tm, tiles_n, 0, tag);
+  };
+  if (dtype == SMN_F64) SMN_TRY(set_lds_attrs<double>(ctx));
+  else SMN_TRY(set_lds_attrs<float>(ctx));
+  for (int64_t s0 = 0; s0 < n_factor; s0 += S) {
+    const int64_t s_end = (n_factor - s0 < S) ? n_factor : s0 + S;
+    for (int64_t js = s0; js < s_end; js += PB) {
+      // appended rows only: C = a[n_factor:, js:js+128] -= a[n_factor:, s0:js] * a[js:js+128, s0:js]^T
+      if (js > s0) SMN_TRY(upd(js, s0, js - s0, 1));
+      // panel solve against the prefactored diagonal block; row blocks start at n_factor
+      if (dtype == SMN_F64) {
+        constexpr int XR = PanelCfg<double>::XR;
+        const unsigned grid = (unsigned)((n_total - n_factor + XR - 1) / XR);
+        hipLaunchKernelGGL(panel_kernel<double>, dim3(grid), dim3(panel_threads(XR)),
+                           panel_lds_bytes<double>(), st, static_cast<double*>(a), lda, js, n_factor,
+                           n_total, 1, ctx->d_scal, ctx->d_info, static_cast<double*>(nullptr), (int64_t)-1, (int64_t)-1);
+      } else {
+        constexpr int XR = PanelCfg<float>::XR;
+        const unsigned grid = (unsigned)((n_total - n_factor + XR - 1) / XR);
+        hipLaunchKernelGGL(panel_kernel<float>, dim3(grid), dim3(panel_threads(XR)),
+                           panel_lds_bytes<float>(), st, static_cast<float*>(a), lda, js, n_factor,
+                           n_total, 1, ctx->d_scal, ctx->d_info, static_cast<float*>(nullptr), (int64_t)-1, (int64_t)-1);
+      }
+      SMN_CHECK_LAUNCH(ctx);
     }
-    // panel solve against the prefactored diagonal block; row blocks start at n_factor
-    if (dtype == SMN_F64) {
-      constexpr int XR = PanelCfg<double>::XR;
-      const unsigned grid = (unsigned)((n_total - n_factor + XR - 1) / XR);
-      hipLaunchKernelGGL(panel_kernel<double>, dim3(grid), dim3(panel_threads(XR)),
-                         panel_lds_bytes<double>(), st, static_cast<double*>(a), lda, js, n_factor,
-                         n_total, 1, ctx->d_scal, ctx->d_info, static_cast<double*>(nullptr), (int64_t)-1, (int64_t)-1);
-    } else {
-      constexpr int XR = PanelCfg<float>::XR;
-      const unsigned grid = (unsigned)((n_total - n_factor + XR - 1) / XR);
-      hipLaunchKernelGGL(panel_kernel<float>, dim3(grid), dim3(panel_threads(XR)),
-                         panel_lds_bytes<float>(), st, static_cast<float*>(a), lda, js, n_factor,
-                         n_total, 1, ctx->d_scal, ctx->d_info, static_cast<float*>(nullptr), (int64_t)-1, (int64_t)-1);
-    }
-    SMN_CHECK_LAUNCH(ctx);
+    if (s_end < n_factor) SMN_TRY(upd(s_end, s0, s_end - s0, (n_factor - s_end) / kTile));
   }
   return SMN_OK;
 }
