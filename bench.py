@@ -606,12 +606,15 @@ def main():
             ctx.call("smn_comm_init", 1, 0, uid)
         sync = RankSync(ctx, world, rank)
     if world > 1:
-        sync.barrier()                             # every rank has read the id: rank 0 removes the rendezvous files
-        if rank == 0 and not args.rendezvous_file:
-            try:
-                os.unlink(path)
-            except OSError:
-                pass
+        sync.barrier()                             # every rank has read the id (and every status file): rank 0 removes them
+        if rank == 0:
+            if not args.rendezvous_file:
+                try:
+                    os.unlink(path)
+                except OSError:
+                    pass
+            if comm_fallback is None:              # (the file rendezvous of the fall-back keeps using the directory)
+                shutil.rmtree(rank_dir, ignore_errors=True)
 
     if args.config == "c3":
         bench_conv(args, out_fd, L, ctx, sync, rank, world)
