@@ -751,6 +751,38 @@ def test_trsm_lower(L, ctx, dtype):
     assert relerr_norm(bd.numpy(), sla.cho_solve((l, True), b)) < (1e-8 if dtype == np.float64 else 5e-3)
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_trsm_across_super_panels(L, ctx, dtype):
+    """The solve-only sweep is two-level (left-looking inside a 1024-column super-panel, one far update of every later column
+    behind it): a matrix of several super-panels, ragged in both dimensions, a strided right-hand side."""
+    rng = np.random.default_rng(112)
+    n, r, ldb = 2700, 205, 260
+    l = np.linalg.cholesky(_spd(rng, n, np.float64, cond=50.0))
+    b = rng.standard_normal((n, ldb))
+    ld = ctx.to_device(l.astype(dtype)); bd = ctx.to_device(b.astype(dtype))
+    ctx.call("smn_trsm", L.dtype_code(dtype), ld.ptr, n, n, bd.ptr, r, ldb, 0)
+    got = bd.numpy()
+    ref = sla.solve_triangular(l, b[:, :r], lower=True)
+    assert relerr_norm(got[:, :r], ref) < (1e-9 if dtype == np.float64 else 2e-3)
+    assert np.array_equal(got[:, r:], b[:, r:].astype(dtype))                 # columns beyond nrhs are not touched
+    ctx.call("smn_trsm", L.dtype_code(dtype), ld.ptr, n, n, bd.ptr, r, ldb, 1)
+    assert relerr_norm(bd.numpy()[:, :r], sla.cho_solve((l, True), b[:, :r])) < (1e-8 if dtype == np.float64 else 5e-3)
+
+
+def test_transpose_entry_point(L, ctx):
+    rng = np.random.default_rng(113)
+    for dtype, rows, cols, lds, ldd in ((np.float32, 37, 70, 75, 40), (np.float64, 130, 33, 33, 130), (np.float32, 1, 1, 1, 1)):
+        a = rng.standard_normal((rows, lds)).astype(dtype)
+        out = np.full((cols, ldd), 7.0, dtype=dtype)
+        ad, od = ctx.to_device(a), ctx.to_device(out)
+        ctx.call("smn_transpose", L.dtype_code(dtype), od.ptr, ldd, ad.ptr, lds, rows, cols)
+        got = od.numpy()
+        assert np.array_equal(got[:, :rows], a[:, :cols].T)
+        assert np.all(got[:, rows:] == 7.0)
+    with pytest.raises(L.SmnError):
+        ctx.call("smn_transpose", L.dtype_code(np.float32), od.ptr, 0, ad.ptr, 1, 1, 1)
+
+
 # ----------------------------------------------------------------------------- heads
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_lml_gaussian_and_student_t(L, ctx, dtype):
