@@ -1135,6 +1135,18 @@ def test_gradient_factorisation_launches_only_the_live_tiles_of_the_identity_blo
         fl += v.value
     assert np.isfinite(loss) and all(np.isfinite(g) for g in grads.values())
     assert 0.9 * n ** 3 < fl < 1.45 * n ** 3, fl / n ** 3      # whole 128 x 128 tiles: a little above N^3 at this size
+    # at this size the joint factorisation runs with the look-ahead (two streams, CU mask) AND the launch split: its loss must
+    # be SPR.loss's, and its w_std gradient the central difference of SPR.loss (the one-stream, un-hinted factorisation)
+    assert abs(loss - model.loss()) < 2e-5 * abs(loss)
+    name = [k for k in grads if k.endswith("w_std") and "last" not in k][0]
+    raw, h = kernel.w_std.value.copy(), 2e-2
+    kernel.w_std.value = raw + h
+    lp = model.loss()
+    kernel.w_std.value = raw - h
+    lm = model.loss()
+    kernel.w_std.value = raw
+    fd = (lp - lm) / (2 * h)
+    assert abs(grads[name] - fd) < 0.03 * abs(fd) + 2e-4, (grads[name], fd)
 
 
 def test_device_matrix_hands_over_its_diagonal_without_a_full_download():
