@@ -62,7 +62,8 @@ int smn_timer_stop_ms(smn_ctx* ctx, double* ms);           /* synchronises */
 /* per-kernel timing: while enabled kernel launches are bracketed by a hipEvent pair on their own
  * stream.  category: 0 prep (pad/tables), 1 fused Gram+recursion build, 2 stand-alone recursion,
  * 3 Cholesky panel, 4 Cholesky strip update, 5 Cholesky trailing update, 6 other (scatter of gathered blocks),
- * 7 all-gathers, 8 the wait of the main stream for the last piece of a pipelined exchange (its exposed part).
+ * 7 all-gathers, 8 the wait of the main stream for the last piece of a pipelined exchange (its exposed part),
+ * 9 the wait of the main stream for the builds of a pipelined exchange's pieces (they run on two build streams: their wall time).
  * on: 0 off; 1 every category; (2 << c) only category c (values add up to a mask).  An event pair
  * costs a few microseconds of queue time per launch, so timing ONE category perturbs a step far less
  * than timing all ~280 launches of it. */

@@ -26,6 +26,13 @@ struct smn_ctx {
   int comm_cus = 16;                  // env SMN_COMM_CUS (0: sharded builds stay on the main stream); 8-32 keep the XCDs balanced (profiles/r02_xcc_placement_probe.txt)
   bool comm_cus_force = false;        // env SMN_COMM_CUS_FORCE=1: mask the sharded build without a multi-rank communicator too (one-GPU rehearsal)
   hipEvent_t ev_b0 = nullptr, ev_b1 = nullptr;   // main -> build stream, build stream -> main
+  // Pieces of a pipelined sharded build (between smn_shard_begin and smn_lml_from_shards) alternate between two masked build
+  // streams and are NOT joined into the main stream one by one: the tail of one piece's launch (a few hundred tiles are about
+  // one tile per CU) runs under the head of the next.  ev_bd[i] = the last build launched on build stream i.
+  hipStream_t stream_build2 = nullptr;
+  hipEvent_t ev_bd[2] = {nullptr, nullptr};
+  unsigned build_seq = 0;
+  unsigned builds_pending = 0;   // bit i: ev_bd[i] has been recorded since the last join
   hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
   hipEvent_t ev_c0 = nullptr, ev_c1 = nullptr;   // main -> comm (piece built), comm -> main (all pieces scattered)
   // factorisation workspace prepared by smn_shard_begin for the pipelined exchange (slot 2)
@@ -53,7 +60,7 @@ struct smn_ctx {
   std::vector<hipEvent_t> prof_ev;   // pool, used pairwise
   std::vector<int> prof_cat;         // category of pair i
   size_t prof_used = 0;              // events handed out
-  double prof_flops[10] = {};         // MFMA flops EXECUTED per category since smn_profile_enable (whole tiles; host-side count)
+  double prof_flops[12] = {};         // MFMA flops EXECUTED per category since smn_profile_enable (whole tiles; host-side count)
   int num_cu = 256;                  // hipDeviceProp_t::multiProcessorCount
   int64_t super_panel = 1024;        // columns per super-panel of the two-level Cholesky (env SMN_SUPER)
   int64_t super_panel_wide = 2048;   // ... while at least super_wide_rows rows are left (env SMN_SUPER_WIDE, SMN_SUPER_WIDE_ROWS)
@@ -74,7 +81,7 @@ struct smn_ctx {
 };
 
 enum { PROF_PREP = 0, PROF_BUILD = 1, PROF_RECURSION = 2, PROF_PANEL = 3, PROF_STRIP = 4, PROF_TRAIL = 5,
-       PROF_MISC = 6, PROF_COMM = 7, PROF_EXPOSED = 8, PROF_NCAT = 9 };
+       PROF_MISC = 6, PROF_COMM = 7, PROF_EXPOSED = 8, PROF_BUILD_WAIT = 9, PROF_NCAT = 10 };
 
 // Brackets the launches issued during its lifetime with an event pair when profiling is on.
 struct ProfScope {

@@ -237,11 +237,31 @@ extern "C" int smn_lml_from_blocks(smn_ctx* ctx, int dtype, const void* stage_d,
 //   smn_shard_exchange_part    that piece: all-gather + scatter into the workspace, on the communication stream,
 //                              ordered after the build launches issued so far -- the next piece's build runs beside it
 //   smn_lml_from_shards        the context's stream waits for the last piece, then the factorisation and the head
+// Builds of a pipelined exchange that have not been joined yet (kernel_build.hip launch_build_t): `st` waits for them.
+static int wait_pending_builds(smn_ctx* ctx, hipStream_t st, bool clear) {
+  if (!ctx->builds_pending) return SMN_OK;
+  auto waits = [&]() -> int {
+    for (int i = 0; i < 2; ++i)
+      if (ctx->builds_pending & (1u << i)) SMN_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_bd[i], 0));
+    return SMN_OK;
+  };
+  if (st == ctx->stream) {
+    // on the main stream this wait IS the wall time of the pieces' builds (the stream has been idle since smn_shard_begin)
+    ProfScope ps(ctx, PROF_BUILD_WAIT, st);
+    SMN_TRY(waits());
+  } else {
+    SMN_TRY(waits());
+  }
+  if (clear) ctx->builds_pending = 0;
+  return SMN_OK;
+}
+
 extern "C" int smn_shard_begin(smn_ctx* ctx, int dtype, int64_t n) {
   if (!ctx) return SMN_EINVAL;
   SMN_ENTER(ctx);
   if (dtype != SMN_F32 && dtype != SMN_F64) return smn_fail(ctx, SMN_EINVAL, "bad dtype");
   if (n <= 0) return smn_fail(ctx, SMN_EINVAL, "smn_shard_begin: empty");
+  SMN_TRY(wait_pending_builds(ctx, ctx->stream, true));   // (an abandoned pipeline's builds)
   Aug g;
   SMN_TRY(aug_alloc(ctx, dtype, n, 0, 1, &g));
   SMN_HIP(ctx, hipMemsetAsync(g.at(n, 0), 0, g.es * (size_t)(g.n_total - n) * (size_t)g.lda, ctx->stream));
@@ -265,6 +285,7 @@ extern "C" int smn_shard_exchange_part(smn_ctx* ctx, int dtype, const void* mine
   hipStream_t sc = ctx->stream_comm;
   SMN_HIP(ctx, hipEventRecord(ctx->ev_c0, ctx->stream));      // the piece is built (and, for part 0, the workspace is up)
   SMN_HIP(ctx, hipStreamWaitEvent(sc, ctx->ev_c0, 0));
+  SMN_TRY(wait_pending_builds(ctx, sc, false));                // ... on a build stream, if the pieces are not joined one by one
   {
     ProfScope ps(ctx, PROF_COMM, sc);
     SMN_TRY(allgather_part_on(ctx, sc, dtype, mine_d, stage_d, chunk, parts, part));
@@ -293,6 +314,7 @@ extern "C" int smn_shard_exchange_part_to(smn_ctx* ctx, int dtype, const void* m
   hipStream_t sc = ctx->stream_comm;
   SMN_HIP(ctx, hipEventRecord(ctx->ev_c0, ctx->stream));
   SMN_HIP(ctx, hipStreamWaitEvent(sc, ctx->ev_c0, 0));
+  SMN_TRY(wait_pending_builds(ctx, sc, false));
   {
     ProfScope ps(ctx, PROF_COMM, sc);
     SMN_TRY(allgather_part_on(ctx, sc, dtype, mine_d, stage_d, chunk, parts, part));
@@ -310,6 +332,7 @@ extern "C" int smn_shard_exchange_part_to(smn_ctx* ctx, int dtype, const void* m
 extern "C" int smn_shard_wait(smn_ctx* ctx) {
   if (!ctx) return SMN_EINVAL;
   SMN_ENTER(ctx);
+  SMN_TRY(wait_pending_builds(ctx, ctx->stream, true));
   ProfScope ps(ctx, PROF_EXPOSED, ctx->stream);
   SMN_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_c1, 0));
   return SMN_OK;
@@ -322,8 +345,9 @@ extern "C" int smn_lml_from_shards(smn_ctx* ctx, int dtype, int64_t n, const voi
   if (!ctx->shard_a || ctx->shard_n != n || ctx->shard_dtype != dtype)
     return smn_fail(ctx, SMN_EINVAL, "smn_lml_from_shards: smn_shard_begin(dtype, n) first");
   if (df > 0.0 && !(scale > 0.0)) return smn_fail(ctx, SMN_EINVAL, "smn_lml_from_shards: scale must be > 0");
+  SMN_TRY(wait_pending_builds(ctx, ctx->stream, true));   // the pieces' builds first (they ran on the build streams) ...
   {
-    // what of the exchange is NOT hidden behind the build: the time this stream spends waiting for the last piece
+    // ... so that this measures what of the exchange is NOT hidden behind the build: the wait for the last piece
     ProfScope ps(ctx, PROF_EXPOSED, ctx->stream);
     SMN_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_c1, 0));
   }
