@@ -296,7 +296,13 @@ extern "C" int smn_ctx_create(int device_id, smn_ctx** out) {
   if (const char* e = getenv("SMN_COMM_CUS_FORCE")) c->comm_cus_force = e[0] == '1';
   if (c->comm_cus > 0 && c->comm_cus < c->num_cu) {
     if (!masked_stream(&c->stream_build, c->comm_cus, c->num_cu)) c->stream_build = nullptr;  // builds stay on the main stream then
-    if (c->stream_build && !masked_stream(&c->stream_build2, c->comm_cus, c->num_cu)) c->stream_build2 = nullptr;   // pieces stay serial then
+    int want = 2;   // two is the measured best: a third and fourth masked queue slow even a single launch down (r03_shard_pieces_probe.json)
+    if (const char* e = getenv("SMN_BUILD_STREAMS")) want = atoi(e);
+    if (want > smn_ctx::kBuildStreams) want = smn_ctx::kBuildStreams;
+    for (int i = 0; c->stream_build && i < want - 1; ++i) {   // (pieces stay serial if none comes up)
+      if (!masked_stream(&c->stream_bx[i], c->comm_cus, c->num_cu)) { c->stream_bx[i] = nullptr; break; }
+      c->n_build_streams = i + 2;
+    }
   }
   bool ok = main_ok &&
             hipEventCreateWithFlags(&c->ev_a, hipEventDisableTiming) == hipSuccess &&
@@ -308,6 +314,8 @@ extern "C" int smn_ctx_create(int device_id, smn_ctx** out) {
             hipEventCreateWithFlags(&c->ev_b1, hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&c->ev_bd[0], hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&c->ev_bd[1], hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&c->ev_bd[2], hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&c->ev_bd[3], hipEventDisableTiming) == hipSuccess &&
             hipEventCreate(&c->ev_t0) == hipSuccess && hipEventCreate(&c->ev_t1) == hipSuccess &&
             hipMalloc(reinterpret_cast<void**>(&c->d_scal), 64 * sizeof(double)) == hipSuccess &&
             hipMalloc(reinterpret_cast<void**>(&c->d_info), 16 * sizeof(int)) == hipSuccess &&
@@ -326,7 +334,8 @@ extern "C" int smn_ctx_destroy(smn_ctx* c) {
   (void)hipSetDevice(c->device);
   if (c->stream_bulk) (void)hipStreamSynchronize(c->stream_bulk);
   if (c->stream_build) (void)hipStreamSynchronize(c->stream_build);
-  if (c->stream_build2) (void)hipStreamSynchronize(c->stream_build2);
+  for (hipStream_t s : c->stream_bx)
+    if (s) (void)hipStreamSynchronize(s);
   if (c->stream_comm) (void)hipStreamSynchronize(c->stream_comm);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->comm) smn_comm_destroy(c);
@@ -342,7 +351,8 @@ extern "C" int smn_ctx_destroy(smn_ctx* c) {
   if (c->ev_c1) (void)hipEventDestroy(c->ev_c1);
   if (c->stream_comm) (void)hipStreamDestroy(c->stream_comm);
   if (c->stream_build) (void)hipStreamDestroy(c->stream_build);
-  if (c->stream_build2) (void)hipStreamDestroy(c->stream_build2);
+  for (hipStream_t s : c->stream_bx)
+    if (s) (void)hipStreamDestroy(s);
   if (c->ev_b0) (void)hipEventDestroy(c->ev_b0);
   if (c->ev_b1) (void)hipEventDestroy(c->ev_b1);
   for (hipEvent_t e : c->ev_bd)

@@ -26,11 +26,13 @@ struct smn_ctx {
   int comm_cus = 16;                  // env SMN_COMM_CUS (0: sharded builds stay on the main stream); 8-32 keep the XCDs balanced (profiles/r02_xcc_placement_probe.txt)
   bool comm_cus_force = false;        // env SMN_COMM_CUS_FORCE=1: mask the sharded build without a multi-rank communicator too (one-GPU rehearsal)
   hipEvent_t ev_b0 = nullptr, ev_b1 = nullptr;   // main -> build stream, build stream -> main
-  // Pieces of a pipelined sharded build (between smn_shard_begin and smn_lml_from_shards) alternate between two masked build
+  // Pieces of a pipelined sharded build (between smn_shard_begin and smn_lml_from_shards) rotate over the masked build
   // streams and are NOT joined into the main stream one by one: the tail of one piece's launch (a few hundred tiles are about
   // one tile per CU) runs under the head of the next.  ev_bd[i] = the last build launched on build stream i.
-  hipStream_t stream_build2 = nullptr;
-  hipEvent_t ev_bd[2] = {nullptr, nullptr};
+  static constexpr int kBuildStreams = 4;   // stream_build + the three below (fewer if their creation failed)
+  hipStream_t stream_bx[kBuildStreams - 1] = {nullptr, nullptr, nullptr};
+  int n_build_streams = 1;
+  hipEvent_t ev_bd[kBuildStreams] = {nullptr, nullptr, nullptr, nullptr};
   unsigned build_seq = 0;
   unsigned builds_pending = 0;   // bit i: ev_bd[i] has been recorded since the last join
   hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;

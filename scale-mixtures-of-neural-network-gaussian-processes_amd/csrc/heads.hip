@@ -241,7 +241,7 @@ extern "C" int smn_lml_from_blocks(smn_ctx* ctx, int dtype, const void* stage_d,
 static int wait_pending_builds(smn_ctx* ctx, hipStream_t st, bool clear) {
   if (!ctx->builds_pending) return SMN_OK;
   auto waits = [&]() -> int {
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < smn_ctx::kBuildStreams; ++i)
       if (ctx->builds_pending & (1u << i)) SMN_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_bd[i], 0));
     return SMN_OK;
   };

@@ -446,13 +446,13 @@ int launch_build_t(smn_ctx* ctx, const BuildArgs<T>& a, int64_t ntiles, size_t l
   // CU with two workgroups it would only run as the build drains -- the exposed exchange would be the whole exchange, not the
   // last piece.  Same order as on the main stream (an event either side).
   const bool masked = a.shard && ctx->stream_build && ctx->comm_cus > 0 && ((ctx->comm && ctx->nranks > 1) || ctx->comm_cus_force);
-  // Inside a pipelined exchange (smn_shard_begin ... smn_lml_from_shards) the pieces alternate between the two build streams
+  // Inside a pipelined exchange (smn_shard_begin ... smn_lml_from_shards) the pieces rotate over the build streams
   // and the main stream does not wait for them one by one: whoever consumes a piece waits for it (smn_shard_exchange_part
   // makes the communication stream wait for ev_bd, smn_lml_from_shards / smn_shard_wait the main stream).  Anywhere else
   // the build joins the main stream at once, as a launch on it would.
-  const bool piecewise = masked && ctx->shard_a != nullptr && ctx->stream_build2 != nullptr;
-  const int bi = piecewise ? (int)(ctx->build_seq++ & 1u) : 0;
-  hipStream_t st = masked ? (bi ? ctx->stream_build2 : ctx->stream_build) : ctx->stream;
+  const bool piecewise = masked && ctx->shard_a != nullptr && ctx->n_build_streams > 1;
+  const int bi = piecewise ? (int)(ctx->build_seq++ % (unsigned)ctx->n_build_streams) : 0;
+  hipStream_t st = masked ? (bi ? ctx->stream_bx[bi - 1] : ctx->stream_build) : ctx->stream;
   if (masked) {
     SMN_HIP(ctx, hipEventRecord(ctx->ev_b0, ctx->stream));
     SMN_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_b0, 0));
