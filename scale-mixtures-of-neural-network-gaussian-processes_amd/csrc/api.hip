@@ -294,6 +294,7 @@ extern "C" int smn_ctx_create(int device_id, smn_ctx** out) {
   }
   if (const char* e = getenv("SMN_COMM_CUS")) c->comm_cus = atoi(e);
   if (const char* e = getenv("SMN_COMM_CUS_FORCE")) c->comm_cus_force = e[0] == '1';
+  if (const char* e = getenv("SMN_SHARD_HALF_TILES")) c->shard_half_tiles_max = atol(e);
   if (c->comm_cus > 0 && c->comm_cus < c->num_cu) {
     if (!masked_stream(&c->stream_build, c->comm_cus, c->num_cu)) c->stream_build = nullptr;  // builds stay on the main stream then
     int want = 2;   // two is the measured best: a third and fourth masked queue slow even a single launch down (r03_shard_pieces_probe.json)

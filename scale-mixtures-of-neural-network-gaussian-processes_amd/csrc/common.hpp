@@ -33,6 +33,7 @@ struct smn_ctx {
   hipStream_t stream_bx[kBuildStreams - 1] = {nullptr, nullptr, nullptr};
   int n_build_streams = 1;
   hipEvent_t ev_bd[kBuildStreams] = {nullptr, nullptr, nullptr, nullptr};
+  int64_t shard_half_tiles_max = 600;   // sharded f32 build launches of at most this many 128x128 tiles use 64-row half tiles (env SMN_SHARD_HALF_TILES; 0: never)
   unsigned build_seq = 0;
   unsigned builds_pending = 0;   // bit i: ev_bd[i] has been recorded since the last join
   hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;

@@ -106,16 +106,23 @@ struct BuildArgs {
   int shard; int sh_b0[2]; int sh_cnt0; T* sh_k[2]; T* sh_t[2]; int64_t sh_ld[2]; int64_t sh_cols[2];
 };
 
-template <typename T, int NET, int ACT, bool NTK>
-__global__ void __launch_bounds__(256, (sizeof(T) == 8 && NTK) ? 1 : 2) build_kernel(BuildArgs<T> a) {
+// BM = 64 (sharded f32 builds of few tiles only): two workgroups per 128x128 tile, 64 rows each -- a piece of a pipelined shard is
+// about one 128x128 tile per CU, and at that grain the launch ends in a tail as long as a tile; halves end in half of it.
+template <typename T, int NET, int ACT, bool NTK, int BM = kTile>
+__global__ void __launch_bounds__(256, (sizeof(T) == 8 && NTK) ? 1 : (BM == 64 ? 3 : 2)) build_kernel(BuildArgs<T> a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  using Tile = MainTile<T>;
+  using Tile = TileNT<T, BM, kTile, SMN_STAGES>;
   using M = typename Tile::M;
-  int tr, tc;
+  static_assert(BM == kTile || BM == 64, "row tile: 128 or 64");
+  int tr, tc, half = 0;
   T* out_k = a.out_k; T* out_t = a.out_t;
   int64_t ldo = a.ldo, out_cols = a.out_cols;
   if (a.shard) {
     int idx = blockIdx.x;
+    if (BM == 64) {
+      half = idx & 1;
+      idx >>= 1;
+    }
     const int w = idx >= a.sh_cnt0 ? 1 : 0;
     if (w) idx -= a.sh_cnt0;
     const int b0 = w ? a.sh_b0[1] : a.sh_b0[0];
@@ -139,7 +146,7 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 8 && NTK) ? 1 : 2) build_ke
     tc = blockIdx.x % a.tiles_n;
     if (a.lower_skip && (int64_t)tc * kTile + a.col_off > (int64_t)tr * kTile + a.row_off + kTile - 1) return;
   }
-  const int64_t row0 = (int64_t)tr * kTile, col0 = (int64_t)tc * kTile;
+  const int64_t row0 = (int64_t)tr * kTile + half * BM, col0 = (int64_t)tc * kTile;
   Tile t;
   t.zero();
   // a tile of the augmented matrix with no valid row or no valid column is pure identity padding (the y-row tile
@@ -163,7 +170,7 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 8 && NTK) ? 1 : 2) build_ke
   for (int idx = tid; idx < trows * kTile; idx += 256) {
     const int s2 = idx / kTile, r = idx % kTile;
     const int g2 = s2 < nsets * 2 ? s2 : nsets * 2 + 1;
-    srow[idx] = a.tab1[(int64_t)g2 * a.ldt1 + row0 + r];
+    if (r < BM) srow[idx] = a.tab1[(int64_t)g2 * a.ldt1 + row0 + r];
     scol[idx] = a.tab2[(int64_t)g2 * a.ldt2 + col0 + r];
   }
   __syncthreads();
@@ -437,9 +444,13 @@ void set_fast(LayerProg* p, bool ntk) {
   p->fast = (sizeof(T) == 4 && p->net == NET_MLP && p->act == ACT_RELU && !ntk) ? 1 : 0;
 }
 
-template <typename T, int NET, int ACT, bool NTK>
+template <typename T, int NET, int ACT, bool NTK, int BM = kTile>
 int launch_build_t(smn_ctx* ctx, const BuildArgs<T>& a, int64_t ntiles, size_t lds) {
-  auto kern = build_kernel<T, NET, ACT, NTK>;
+  auto kern = build_kernel<T, NET, ACT, NTK, BM>;
+  if (BM == 64) {
+    ntiles *= 2;
+    lds = std::max<size_t>(TileNT<T, 64, kTile, SMN_STAGES>::LDS_BYTES, (size_t)(a.prog.nsets * 2 + 1) * 2 * kTile * sizeof(T));
+  }
   SMN_TRY(smn_allow_lds(ctx, reinterpret_cast<const void*>(kern), lds));
   // A sharded build beside a live exchange (communicator of more than one rank, or SMN_COMM_CUS_FORCE for rehearsals) goes to
   // the stream whose CU mask leaves comm_cus CUs alone: RCCL's all-gather is a kernel too, and behind a build that fills every
@@ -474,6 +485,15 @@ int launch_build_t(smn_ctx* ctx, const BuildArgs<T>& a, int64_t ntiles, size_t l
 
 template <typename T, int NET, int ACT>
 int launch_build_n(smn_ctx* ctx, const BuildArgs<T>& a, int64_t ntiles, size_t lds, bool ntk) {
+  if constexpr (sizeof(T) == 4) {
+    // sharded f32 launches (pieces of a pipelined shard, a rank's share of the build): 64-row half tiles.  Measured per rank on
+    // 240 CUs (profiles/r03_shard_pieces_probe.json): 11-17 % faster for pieces of 260-520 tiles (the default pieces at 2, 4 and 8
+    // GPUs), a few % either way around 1000 tiles; the un-sharded 8392-tile build of one GPU is 5 % SLOWER with them (6.97 against
+    // 6.6 ms) and so are the eight 1032-tile pieces of the one-rank rehearsal: launches above 600 tiles keep the 128-row tile.
+    if (a.shard && ntiles <= ctx->shard_half_tiles_max)
+      return ntk ? launch_build_t<T, NET, ACT, true, 64>(ctx, a, ntiles, lds)
+                 : launch_build_t<T, NET, ACT, false, 64>(ctx, a, ntiles, lds);
+  }
   return ntk ? launch_build_t<T, NET, ACT, true>(ctx, a, ntiles, lds)
              : launch_build_t<T, NET, ACT, false>(ctx, a, ntiles, lds);
 }
