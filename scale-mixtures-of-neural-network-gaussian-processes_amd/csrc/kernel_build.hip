@@ -93,7 +93,7 @@ __global__ void diag_tables_kernel(const double* __restrict__ q0, int64_t n, Lay
 template <typename T>
 struct BuildArgs {
   const T* x1; const T* x2; int64_t ld1, ld2; int kp;
-  int tiles_n; int symmetric; int mirror;
+  int tiles_n; int tiles_m; int symmetric; int mirror;
   int lower_skip;             // rectangular grid: drop tiles lying wholly above the global diagonal
   const T* tab1; const T* tab2; int64_t ldt1, ldt2; const T* dg; const T* dgt;
   T inv_d; LayerProg prog;
@@ -137,14 +137,23 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 8 && NTK) ? 1 : (BM == 64 ?
     out_t = w ? a.sh_t[1] : a.sh_t[0];
     if (out_k) out_k -= (int64_t)b0 * kTile * ldo;
     if (out_t) out_t -= (int64_t)b0 * kTile * ldo;
-  } else if (a.use_map) {
-    if (!a.map.decode(blockIdx.x, tr, tc)) return;
-  } else if (a.symmetric) {
-    tri_decode(blockIdx.x, tr, tc);
   } else {
-    tr = blockIdx.x / a.tiles_n;
-    tc = blockIdx.x % a.tiles_n;
-    if (a.lower_skip && (int64_t)tc * kTile + a.col_off > (int64_t)tr * kTile + a.row_off + kTile - 1) return;
+    unsigned bid = blockIdx.x;
+    if (BM == 64) {   // (grids padded to a multiple of 8 tiles) both halves of a tile on the same XCD: workgroups b and b + 8 share one
+      half = (bid >> 3) & 1;
+      bid = ((bid >> 4) << 3) | (bid & 7);
+    }
+    if (a.use_map) {
+      if (!a.map.decode(bid, tr, tc)) return;
+    } else if (a.symmetric) {
+      if (bid >= (unsigned)(a.tiles_n * (a.tiles_n + 1) / 2)) return;
+      tri_decode(bid, tr, tc);
+    } else {
+      tr = bid / a.tiles_n;
+      tc = bid % a.tiles_n;
+      if (tr >= a.tiles_m) return;
+      if (a.lower_skip && (int64_t)tc * kTile + a.col_off > (int64_t)tr * kTile + a.row_off + kTile - 1) return;
+    }
   }
   const int64_t row0 = (int64_t)tr * kTile + half * BM, col0 = (int64_t)tc * kTile;
   Tile t;
@@ -486,13 +495,16 @@ int launch_build_t(smn_ctx* ctx, const BuildArgs<T>& a, int64_t ntiles, size_t l
 template <typename T, int NET, int ACT>
 int launch_build_n(smn_ctx* ctx, const BuildArgs<T>& a, int64_t ntiles, size_t lds, bool ntk) {
   if constexpr (sizeof(T) == 4) {
-    // sharded f32 launches (pieces of a pipelined shard, a rank's share of the build): 64-row half tiles.  Measured per rank on
+    // f32 launches of few tiles (pieces of a pipelined shard, a rank's share of the build, small kernels): 64-row half tiles.  Measured per rank on
     // 240 CUs (profiles/r03_shard_pieces_probe.json): 11-17 % faster for pieces of 260-520 tiles (the default pieces at 2, 4 and 8
     // GPUs), a few % either way around 1000 tiles; the un-sharded 8392-tile build of one GPU is 5 % SLOWER with them (6.97 against
     // 6.6 ms) and so are the eight 1032-tile pieces of the one-rank rehearsal: launches above 600 tiles keep the 128-row tile.
-    if (a.shard && ntiles <= ctx->shard_half_tiles_max)
+    // (un-sharded launches too, from 64 tiles on: C2's 528-tile build 0.144 -> 0.118 ms; below that nothing to balance)
+    if (ntiles <= ctx->shard_half_tiles_max && (a.shard || ntiles >= 64)) {
+      if (!a.shard) ntiles = (ntiles + 7) / 8 * 8;   // the un-sharded decode pairs the halves inside groups of 16 workgroups
       return ntk ? launch_build_t<T, NET, ACT, true, 64>(ctx, a, ntiles, lds)
                  : launch_build_t<T, NET, ACT, false, 64>(ctx, a, ntiles, lds);
+    }
   }
   return ntk ? launch_build_t<T, NET, ACT, true>(ctx, a, ntiles, lds)
              : launch_build_t<T, NET, ACT, false>(ctx, a, ntiles, lds);
@@ -539,7 +551,7 @@ int run_build_t(smn_ctx* ctx, const BuildCall& c) {
   a.x1 = static_cast<const T*>(c.x1p); a.x2 = static_cast<const T*>(c.x2p);
   a.ld1 = c.ld1; a.ld2 = c.ld2; a.kp = c.kp;
   const int64_t tm = c.rows1 / kTile, tn = c.rows2 / kTile;
-  a.tiles_n = (int)tn; a.symmetric = c.symmetric; a.mirror = c.mirror;
+  a.tiles_n = (int)tn; a.tiles_m = (int)tm; a.symmetric = c.symmetric; a.mirror = c.mirror;
   a.lower_skip = (!c.symmetric && c.lower_skip) ? 1 : 0;
   a.tab1 = tab1; a.tab2 = tab2; a.ldt1 = tlen; a.ldt2 = tlen; a.dg = dg1; a.dgt = dgt1;
   a.inv_d = (T)(1.0 / (double)c.d); a.prog = prog;
