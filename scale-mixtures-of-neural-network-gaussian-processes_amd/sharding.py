@@ -131,11 +131,12 @@ def _check_communicator(ctx, world):
 
 def default_parts(n: int, world: int) -> int:
     """Pieces per chunk.  A piece's tile rows are one build launch, and a launch of fewer tiles than the chip has CUs
-    leaves CUs idle for a whole tile time (0.2-0.4 ms at d = 3072): at least ~256 tiles per piece, at most 8 pieces,
+    leaves CUs idle for a whole tile time (0.2-0.4 ms at d = 3072): at least ~256 tiles per piece, at most 8 pieces (16 on
+    two ranks, where the exchange over the single link takes as long as the build and what is exposed is one piece of it),
     a power of two that cuts the chunk into multiples of 4 elements."""
     t = -(-n // TILE)
     tiles_per_rank = t * (t + 1) // 2 // world
-    p = 8
+    p = 16 if world == 2 else 8
     while p > 1 and tiles_per_rank // p < 256:
         p //= 2
     chunk = paired_chunk_elems(n, world)

@@ -29,7 +29,8 @@ for P in (2, 4, 8):
     mine = ctx.empty((chunk,), np.float32)
     res = {}
     gdef = S.default_parts(n, P)
-    for G in sorted({gdef, max(1, gdef // 2), 1}, reverse=True):
+    extra = {int(g) for g in os.environ.get("SMN_PROBE_G", "").split(",") if g}
+    for G in sorted({gdef, max(1, gdef // 2), 1} | extra, reverse=True):
         per_rank = []
         for r in range(P):
             rows_list = S.part_tile_rows(n, P, r, G)

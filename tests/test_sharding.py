@@ -207,6 +207,7 @@ def test_part_tile_rows_build_every_tile_row_once_before_its_piece_is_gathered()
                     assert done >= min(chunk, (g + 1) * piece)
                 assert built == [tpb, tpb]
     assert S.default_parts(16384, 8) == 4 and S.default_parts(32768, 8) == 8 and S.default_parts(16384, 1) == 8
+    assert S.default_parts(16384, 2) == 16 and S.default_parts(16384, 4) == 8 and S.default_parts(4096, 2) in (1, 2)
     with pytest.raises(ValueError):
         S.part_tile_rows(1000, 3, 0, 5)
 
