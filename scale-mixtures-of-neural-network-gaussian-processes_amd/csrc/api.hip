@@ -11,13 +11,23 @@ int smn_allow_lds(smn_ctx* ctx, const void* kernel, size_t lds) {
   return SMN_OK;
 }
 
+// Every stream of the context other than the main one has drained (before memory they may touch is freed).
+static int sync_side_streams(smn_ctx* ctx) {
+  if (ctx->stream_comm) SMN_HIP(ctx, hipStreamSynchronize(ctx->stream_comm));
+  if (ctx->stream_scatter) SMN_HIP(ctx, hipStreamSynchronize(ctx->stream_scatter));
+  if (ctx->stream_build) SMN_HIP(ctx, hipStreamSynchronize(ctx->stream_build));
+  for (hipStream_t s : ctx->stream_bx)
+    if (s) SMN_HIP(ctx, hipStreamSynchronize(s));
+  return SMN_OK;
+}
+
 int smn_workspace(smn_ctx* ctx, int slot, size_t bytes, void** out) {
   if (slot < 0 || slot >= smn_ctx::kSlots) return smn_fail(ctx, SMN_EINVAL, "bad workspace slot");
   if (slot == 0) ctx->op_x = nullptr;   // whoever asks for slot 0 is about to overwrite the padded operand
   if (ctx->ws_bytes[slot] < bytes) {
     if (slot == 2) ctx->shard_a = nullptr;   // a pipelined exchange in flight must not scatter into the freed buffer
     if (ctx->ws[slot]) {
-      if (ctx->stream_comm) SMN_HIP(ctx, hipStreamSynchronize(ctx->stream_comm));
+      SMN_TRY(sync_side_streams(ctx));
       SMN_HIP(ctx, hipStreamSynchronize(ctx->stream));
       SMN_HIP(ctx, hipFree(ctx->ws[slot]));
       ctx->ws[slot] = nullptr;
@@ -311,6 +321,8 @@ extern "C" int smn_ctx_create(int device_id, smn_ctx** out) {
             hipEventCreateWithFlags(&c->ev_c0, hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&c->ev_c1, hipEventDisableTiming) == hipSuccess &&
             hipStreamCreateWithPriority(&c->stream_comm, hipStreamNonBlocking, prio_hi) == hipSuccess &&
+            hipStreamCreateWithPriority(&c->stream_scatter, hipStreamNonBlocking, prio_hi) == hipSuccess &&
+            hipEventCreateWithFlags(&c->ev_g, hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&c->ev_b0, hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&c->ev_b1, hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&c->ev_bd[0], hipEventDisableTiming) == hipSuccess &&
@@ -338,6 +350,7 @@ extern "C" int smn_ctx_destroy(smn_ctx* c) {
   for (hipStream_t s : c->stream_bx)
     if (s) (void)hipStreamSynchronize(s);
   if (c->stream_comm) (void)hipStreamSynchronize(c->stream_comm);
+  if (c->stream_scatter) (void)hipStreamSynchronize(c->stream_scatter);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->comm) smn_comm_destroy(c);
   for (int i = 0; i < smn_ctx::kSlots; ++i)
@@ -351,6 +364,8 @@ extern "C" int smn_ctx_destroy(smn_ctx* c) {
   if (c->ev_c0) (void)hipEventDestroy(c->ev_c0);
   if (c->ev_c1) (void)hipEventDestroy(c->ev_c1);
   if (c->stream_comm) (void)hipStreamDestroy(c->stream_comm);
+  if (c->stream_scatter) (void)hipStreamDestroy(c->stream_scatter);
+  if (c->ev_g) (void)hipEventDestroy(c->ev_g);
   if (c->stream_build) (void)hipStreamDestroy(c->stream_build);
   for (hipStream_t s : c->stream_bx)
     if (s) (void)hipStreamDestroy(s);
@@ -392,7 +407,7 @@ extern "C" int smn_free(smn_ctx* ctx, void* dptr) {
   if (!ctx) return SMN_EINVAL;
   SMN_ENTER(ctx);
   if (!dptr) return SMN_OK;
-  if (ctx->stream_comm) SMN_HIP(ctx, hipStreamSynchronize(ctx->stream_comm));   // a piece of it may still be in flight
+  SMN_TRY(sync_side_streams(ctx));   // a piece of it may still be in flight (exchange, scatter, a piece's build)
   SMN_HIP(ctx, hipStreamSynchronize(ctx->stream));
   SMN_HIP(ctx, hipFree(dptr));
   return SMN_OK;

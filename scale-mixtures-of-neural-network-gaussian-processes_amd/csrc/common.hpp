@@ -21,6 +21,8 @@ struct smn_ctx {
   int chain_cus = 32;                 // CUs kept free for the panel chain (env SMN_CHAIN_CUS; 0 = no look-ahead)
   int64_t chain_min_n = 8192;         // look-ahead only from this matrix size on (env SMN_CHAIN_MIN_N)
   int64_t f0_first_tiles = 2000;      // F1 launches of at most this many tiles start behind F0, not beside it (env SMN_F0_FIRST_TILES; 0: never)
+  hipStream_t stream_scatter = nullptr;   // the scatter of a gathered piece into the workspace: beside the NEXT piece's all-gather (link-bound), not in front of it
+  hipEvent_t ev_g = nullptr;              // comm stream -> scatter stream (re-recorded per piece)
   hipStream_t stream_comm = nullptr;  // the pipelined exchange: all-gather + scatter of one piece while the next one is being built (high priority)
   hipStream_t stream_build = nullptr; // sharded builds beside a live exchange: may not use the first comm_cus CUs, which RCCL's kernels then always find free
   int comm_cus = 16;                  // env SMN_COMM_CUS (0: sharded builds stay on the main stream); 8-32 keep the XCDs balanced (profiles/r02_xcc_placement_probe.txt)

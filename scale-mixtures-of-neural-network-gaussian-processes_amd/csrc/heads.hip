@@ -290,11 +290,16 @@ extern "C" int smn_shard_exchange_part(smn_ctx* ctx, int dtype, const void* mine
     ProfScope ps(ctx, PROF_COMM, sc);
     SMN_TRY(allgather_part_on(ctx, sc, dtype, mine_d, stage_d, chunk, parts, part));
   }
+  // The scatter has its own stream: the NEXT piece's all-gather (link-bound) starts as soon as its build is done, not behind
+  // this scatter (HBM-bound, and beside a live build confined to the CUs the build leaves free).
+  hipStream_t ss = ctx->stream_scatter;
+  SMN_HIP(ctx, hipEventRecord(ctx->ev_g, sc));
+  SMN_HIP(ctx, hipStreamWaitEvent(ss, ctx->ev_g, 0));
   {
-    ProfScope ps(ctx, PROF_MISC, sc);
-    SMN_TRY(unpack_parts_on(ctx, sc, dtype, stage_d, n, nranks, block_rows, parts, part, part + 1, ctx->shard_a, ctx->shard_lda));
+    ProfScope ps(ctx, PROF_MISC, ss);
+    SMN_TRY(unpack_parts_on(ctx, ss, dtype, stage_d, n, nranks, block_rows, parts, part, part + 1, ctx->shard_a, ctx->shard_lda));
   }
-  SMN_HIP(ctx, hipEventRecord(ctx->ev_c1, sc));
+  SMN_HIP(ctx, hipEventRecord(ctx->ev_c1, ss));
   return SMN_OK;
 }
 
@@ -319,11 +324,14 @@ extern "C" int smn_shard_exchange_part_to(smn_ctx* ctx, int dtype, const void* m
     ProfScope ps(ctx, PROF_COMM, sc);
     SMN_TRY(allgather_part_on(ctx, sc, dtype, mine_d, stage_d, chunk, parts, part));
   }
+  hipStream_t ss = ctx->stream_scatter;
+  SMN_HIP(ctx, hipEventRecord(ctx->ev_g, sc));
+  SMN_HIP(ctx, hipStreamWaitEvent(ss, ctx->ev_g, 0));
   {
-    ProfScope ps(ctx, PROF_MISC, sc);
-    SMN_TRY(unpack_parts_on(ctx, sc, dtype, stage_d, n, nranks, block_rows, parts, part, part + 1, k_d, ldk));
+    ProfScope ps(ctx, PROF_MISC, ss);
+    SMN_TRY(unpack_parts_on(ctx, ss, dtype, stage_d, n, nranks, block_rows, parts, part, part + 1, k_d, ldk));
   }
-  SMN_HIP(ctx, hipEventRecord(ctx->ev_c1, sc));
+  SMN_HIP(ctx, hipEventRecord(ctx->ev_c1, ss));
   return SMN_OK;
 }
 
