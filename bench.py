@@ -11,10 +11,16 @@ fused Gram + layer recursion -> K + eps I -> blocked Cholesky with y carried -> 
                                             hands the 128-byte RCCL id to the others through a file.  No torch, no launcher.
     python -m torch.distributed.run --nproc-per-node P ... bench.py --gpus P    the same workers under an external launcher
 
-With P > 1 the kernel build is row-sharded over the ranks (paired lower-block layout, sharding.py) and the exchange is
-pipelined behind it: every rank's chunk goes out in pieces, each piece all-gathered (RCCL) and scattered into the
-factorisation workspace on a communication stream while the next piece is being built; every rank then factors the
-assembled kernel (strong scaling: total work fixed).
+With P > 1 the kernel build is sharded over the ranks by 128-row tile rows dealt cyclically (sharding.py, cyclic
+column-first layout): every rank builds its share in ONE launch on all CUs, then the exchange goes out column range by
+column range (an RCCL all-gather + a scatter into the factorisation workspace per range, on side streams) while every
+rank is already factoring: the first panel chain waits for the first 1024 columns only (strong scaling: total work fixed;
+the factorisation itself is replicated, so the whole step is Amdahl-bound -- the line states the kernel-build speed-up).
+
+Multi-rank runs are self-diagnosing: every rank keeps a heartbeat (phase + step) in a file; when a rank makes no progress
+for SMN_BENCH_STALL_S (120) seconds or the run exceeds SMN_BENCH_RANK_TIMEOUT_S (240), ONE JSON line names the stuck rank
+and its phase and the run exits non-zero.  When the RCCL communicator cannot be brought up the run exits non-zero too
+(`"comm": {"fallback": reason}`) unless --allow-replica-fallback asks for independent replicas.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
 """
@@ -58,7 +64,9 @@ def parse():
     p.add_argument("--act", default=None)
     p.add_argument("--dtype", default=None, choices=["f32", "f64"])
     p.add_argument("--eps", type=float, default=None)
-    p.add_argument("--parts", type=int, default=0, help="pieces of the pipelined exchange (0: sharding.default_parts)")
+    p.add_argument("--pieces", type=int, default=0, help="column ranges of the exchange (0: sharding.default_col_pieces, at most 16)")
+    p.add_argument("--allow-replica-fallback", action="store_true",
+                   help="P > 1 and no RCCL communicator: run P independent replicas (scaling = \"replicas\") instead of exiting non-zero")
     p.add_argument("--cpu-sample-n", type=int, default=0, help="0: the benched N")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-recursion-probe", action="store_true")
@@ -67,7 +75,7 @@ def parse():
     p.add_argument("--no-other-workloads", action="store_true",
                    help="skip C2 / C5 / C3 / fp64 / predictive-path measurements appended to the default line")
     p.add_argument("--sharded-path", action="store_true",
-                   help="run the P>1 step (sharded build + pipelined exchange + LML) even with one rank (rehearsal on one GPU)")
+                   help="run the P>1 step (sharded build + column-first exchange + LML) even with one rank (rehearsal on one GPU)")
     p.add_argument("--rendezvous-file", default=None, help=argparse.SUPPRESS)
     a = p.parse_args()
     for k, v in CONFIGS[a.config].items():
@@ -77,9 +85,15 @@ def parse():
 
 
 # ----------------------------------------------------------------------------- launcher (no GPU call in this process)
+RANK_TIMEOUT_S = float(os.environ.get("SMN_BENCH_RANK_TIMEOUT_S", "240"))   # whole multi-rank run, per rank, from its start
+RANK_STALL_S = float(os.environ.get("SMN_BENCH_STALL_S", "120"))            # no change of phase / step for this long
+
+
 def launch_ranks(args):
     """`python bench.py --gpus P` without a launcher: P fresh children, one per GPU.  This process never touches a GPU
-    (a GPU-initialised process must not be re-executed), it only waits; the children rendezvous through a file."""
+    (a GPU-initialised process must not be re-executed), it only waits; the children rendezvous through files in a fresh
+    directory.  Every child carries its own watchdog (Watchdog below) and rank 0 prints the diagnosis; this parent only ends
+    the others when one has failed, and prints the diagnosis itself if the children are past their limit without one."""
     tmp = tempfile.mkdtemp(prefix="smnngp_bench_")
     rdv = os.path.join(tmp, "rccl_id")
     procs = []
@@ -87,14 +101,15 @@ def launch_ranks(args):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus))
         cmd = [sys.executable, os.path.abspath(sys.argv[0])] + sys.argv[1:] + ["--rendezvous-file", rdv]   # the script as invoked
         procs.append(subprocess.Popen(cmd, env=env, stdout=None if r == 0 else subprocess.DEVNULL))
-    # wait for all of them; if one fails the others would sit in the communicator's rendezvous for ever: end them (by
-    # their own PIDs) and report the failure
     rc = 0
     alive = list(procs)
-    deadline = time.time() + float(os.environ.get("SMN_BENCH_RANK_TIMEOUT_S", "1500"))   # a rank stuck inside RCCL never exits by itself
+    deadline = time.time() + RANK_TIMEOUT_S + 20.0     # the ranks' own watchdogs fire first
     while alive:
         if time.time() > deadline:
-            sys.stderr.write("bench.py: ranks still running after the wall-clock limit; terminating them\n")
+            if not os.path.exists(os.path.join(rdv + ".run", "line_emitted")):
+                line = diagnose(rdv + ".run", args.gpus, "ranks still running %.0f s after the start" % (RANK_TIMEOUT_S + 20.0))
+                sys.stdout.write(json.dumps(line) + "\n")
+                sys.stdout.flush()
             for q in alive:
                 q.terminate()
             for q in alive:
@@ -111,6 +126,7 @@ def launch_ranks(args):
             alive.remove(p)
             if r != 0 and rc == 0:
                 rc = abs(r) or 1
+                time.sleep(1.0)                       # (rank 0 may be writing the diagnosis)
                 for q in alive:
                     q.terminate()
         if alive:
@@ -119,28 +135,155 @@ def launch_ranks(args):
     sys.exit(rc)
 
 
+def _launcher_start_time():
+    """When the process that started the ranks began (our launcher or torchrun's agent): rendezvous files older than that
+    belong to an earlier run that left them behind (same port, recycled parent PID) and are treated as absent."""
+    try:
+        return os.stat("/proc/%d" % os.getppid()).st_mtime - 2.0
+    except OSError:
+        return 0.0
+
+
+def _read_fresh(path, mode="r"):
+    """Contents of `path`, or None when it is missing or stale (older than the launcher)."""
+    try:
+        if os.stat(path).st_mtime < _launcher_start_time():
+            return None
+        with open(path, mode) as f:
+            return f.read()
+    except (FileNotFoundError, ValueError, OSError):
+        return None
+
+
+def _write_atomic(path, data, mode="w"):
+    with open(path + ".tmp", mode) as f:
+        f.write(data)
+    os.replace(path + ".tmp", path)
+
+
+def diagnose(run_dir, world, why):
+    """The ONE JSON line of a multi-rank run that did not finish: every rank's last heartbeat, and as `stuck_rank` the rank
+    that entered its current phase first (the ranks waiting for it inside a collective arrived later) -- or that never
+    wrote one."""
+    now = time.time()
+    ranks, stuck, oldest = {}, None, None
+    for r in range(world):
+        raw = _read_fresh(os.path.join(run_dir, "hb_%d" % r))
+        try:
+            hb = json.loads(raw) if raw else None
+        except ValueError:
+            hb = None
+        if hb is None:
+            ranks[str(r)] = {"phase": "never started (no heartbeat)", "in_phase_s": None}
+            if oldest is None or oldest > -1.0:
+                stuck, oldest = r, -1.0
+            continue
+        ranks[str(r)] = {"phase": hb["phase"], "in_phase_s": round(now - hb["t_phase"], 1), "heartbeat_age_s": round(now - hb["t"], 1)}
+        if hb["phase"] != "done" and (oldest is None or hb["t_phase"] < oldest):
+            stuck, oldest = r, hb["t_phase"]
+    phase = ranks[str(stuck)]["phase"] if stuck is not None else None
+    return {"metric": "kernel-build + Cholesky wallclock (ms) and GFLOP/s", "value": None, "unit": "GFLOP/s", "n_gpus": world,
+            "error": "multi-rank run did not finish: %s; rank %s stopped first, in phase '%s'" % (why, stuck, phase),
+            "stuck_rank": stuck, "phase": phase, "ranks": ranks, "higher_is_better": True}
+
+
+class Watchdog:
+    """Heartbeat + limits of one rank.  The phase lives in memory (no file I/O in the timed loop); a daemon thread mirrors it
+    into <run_dir>/hb_<rank> four times a second (ctypes releases the GIL, so it runs while the main thread sits in RCCL),
+    reads the other ranks' files and, when a rank has not changed phase for RANK_STALL_S or this rank is past
+    RANK_TIMEOUT_S, ends the run: rank 0 prints the diagnosis (ONE JSON line), every rank exits with status 3.  A
+    GPU-initialised process is never re-executed; it just exits."""
+
+    def __init__(self, run_dir, rank, world, out_fd, limit_s=None, stall_s=None):
+        import threading
+        self.dir, self.rank, self.world, self.out_fd = run_dir, rank, world, out_fd
+        self.limit_s = RANK_TIMEOUT_S if limit_s is None else limit_s
+        self.stall_s = RANK_STALL_S if stall_s is None else stall_s
+        self.t0 = time.time()
+        self._phase, self._t_phase = "init", self.t0
+        self._stop = False
+        os.makedirs(run_dir, exist_ok=True)
+        self._beat()
+        self.thread = threading.Thread(target=self._loop, daemon=True)
+        self.thread.start()
+
+    def phase(self, name):
+        if name != self._phase:
+            self._phase, self._t_phase = name, time.time()
+
+    def _beat(self):
+        _write_atomic(os.path.join(self.dir, "hb_%d" % self.rank),
+                      json.dumps({"phase": self._phase, "t_phase": self._t_phase, "t": time.time()}))
+
+    def _loop(self):
+        while not self._stop:
+            try:
+                self._beat()
+                why = self._expired()
+                if why:
+                    self._end(why)
+            except Exception:   # noqa: BLE001  (a vanished directory at shutdown must not raise in a daemon thread)
+                pass
+            time.sleep(0.25)
+
+    def _expired(self):
+        now = time.time()
+        if now - self.t0 > self.limit_s:
+            return "rank %d past the %.0f s limit (SMN_BENCH_RANK_TIMEOUT_S)" % (self.rank, self.limit_s)
+        other = _read_fresh(os.path.join(self.dir, "expired"))
+        if other is not None:
+            return other or "another rank's watchdog ended the run"       # (that rank's reason)
+        for r in range(self.world):
+            raw = _read_fresh(os.path.join(self.dir, "hb_%d" % r)) if r != self.rank else None
+            t_phase, ph = self._t_phase, self._phase
+            if r != self.rank:
+                if not raw:
+                    continue                          # not started yet: covered by the overall limit
+                try:
+                    hb = json.loads(raw)
+                except ValueError:
+                    continue
+                t_phase, ph = hb["t_phase"], hb["phase"]
+            if ph != "done" and now - t_phase > self.stall_s:
+                return "rank %d made no progress for %.0f s (SMN_BENCH_STALL_S)" % (r, self.stall_s)
+        return None
+
+    def _end(self, why):
+        try:
+            if not os.path.exists(os.path.join(self.dir, "expired")):
+                _write_atomic(os.path.join(self.dir, "expired"), why)
+        except OSError:
+            pass
+        if self.rank == 0:
+            time.sleep(0.6)                           # every rank's last heartbeat is on disk
+            self.out_fd.emit(json.dumps(diagnose(self.dir, self.world, why)))
+            try:
+                _write_atomic(os.path.join(self.dir, "line_emitted"), "1")
+            except OSError:
+                pass
+        else:
+            time.sleep(2.0)                           # rank 0 reads the heartbeats first
+        os._exit(3)
+
+    def done(self):
+        self.phase("done")
+        self._beat()
+        self._stop = True
+
+
 def exchange_rccl_id(L, path, rank, timeout_s=120.0):
-    """Rank 0 creates the 128-byte RCCL id and publishes it with an atomic rename; the others poll for the file."""
+    """Rank 0 creates the 128-byte RCCL id and publishes it with an atomic rename; the others poll for the file (a stale
+    one -- older than the launcher -- is not read)."""
     uid = C.create_string_buffer(128)
     if rank == 0:
         assert L._lib.smn_comm_unique_id(uid) == 0, "RCCL unavailable"
-        try:
-            os.unlink(path)                       # a stale id of an earlier run (same port, recycled parent PID) must not be read
-        except FileNotFoundError:
-            pass
-        with open(path + ".tmp", "wb") as f:
-            f.write(uid.raw)
-        os.replace(path + ".tmp", path)
+        _write_atomic(path, uid.raw, "wb")
         return uid
     t0 = time.time()
     while True:
-        try:
-            with open(path, "rb") as f:
-                raw = f.read()
-            if len(raw) == 128:
-                return C.create_string_buffer(raw, 128)
-        except FileNotFoundError:
-            pass
+        raw = _read_fresh(path, "rb")
+        if raw is not None and len(raw) == 128:
+            return C.create_string_buffer(raw, 128)
         if time.time() - t0 > timeout_s:
             raise RuntimeError("rank %d: no RCCL id at %s after %.0f s" % (rank, path, timeout_s))
         time.sleep(0.02)
@@ -172,27 +315,24 @@ class RankSync:
 
 
 class FileSync:
-    """The same three calls through files in a directory every rank of the node sees: the fall-back when the RCCL
-    communicator cannot be brought up (the step then runs as independent replicas; there is nothing to exchange)."""
+    """The same three calls through files in a directory every rank of the node sees: the replica fall-back when the RCCL
+    communicator cannot be brought up (--allow-replica-fallback; there is nothing to exchange then)."""
 
     def __init__(self, directory, world, rank):
         self.dir, self.world, self.rank, self.k = directory, world, rank, 0
 
     def gather(self, value, timeout_s=600.0):
         self.k += 1
-        mine = os.path.join(self.dir, "g%d_%d" % (self.k, self.rank))
-        with open(mine + ".tmp", "w") as f:
-            f.write(repr(float(value)))
-        os.replace(mine + ".tmp", mine)
+        _write_atomic(os.path.join(self.dir, "g%d_%d" % (self.k, self.rank)), repr(float(value)))
         out, t0 = [], time.time()
         for r in range(self.world):
             path = os.path.join(self.dir, "g%d_%d" % (self.k, r))
             while True:
+                raw = _read_fresh(path)
                 try:
-                    with open(path) as f:
-                        out.append(float(f.read()))
+                    out.append(float(raw))
                     break
-                except (FileNotFoundError, ValueError):
+                except (TypeError, ValueError):
                     if time.time() - t0 > timeout_s:
                         raise RuntimeError("rank %d: rank %d never reached step %d of the file rendezvous" % (self.rank, r, self.k))
                     time.sleep(0.0005)
@@ -205,31 +345,26 @@ class FileSync:
         return max(self.gather(value))
 
 
-def agree_on_communicator(path, world, rank, ok, timeout_s=180.0):
-    """Every rank publishes whether its smn_comm_init succeeded; all of them read all of them.  Returns (all_ok, directory)."""
-    d = path + ".ranks"
-    os.makedirs(d, exist_ok=True)
-    mine = os.path.join(d, "init_%d" % rank)
-    with open(mine + ".tmp", "w") as f:
-        f.write("1" if ok else "0")
-    os.replace(mine + ".tmp", mine)
+def agree_on_communicator(run_dir, world, rank, ok, timeout_s=180.0):
+    """Every rank publishes whether its smn_comm_init succeeded; all of them read all of them (stale files of an earlier run
+    are not read).  Returns all_ok."""
+    os.makedirs(run_dir, exist_ok=True)
+    _write_atomic(os.path.join(run_dir, "init_%d" % rank), "1" if ok else "0")
     t0, flags = time.time(), []
     for r in range(world):
         while True:
-            try:
-                with open(os.path.join(d, "init_%d" % r)) as f:
-                    flags.append(f.read().strip() == "1")
+            raw = _read_fresh(os.path.join(run_dir, "init_%d" % r))
+            if raw is not None:
+                flags.append(raw.strip() == "1")
                 break
-            except FileNotFoundError:
-                if time.time() - t0 > timeout_s:
-                    raise RuntimeError("rank %d: rank %d did not report its communicator within %.0f s" % (rank, r, timeout_s))
-                time.sleep(0.005)
-    return all(flags), d
+            if time.time() - t0 > timeout_s:
+                raise RuntimeError("rank %d: rank %d did not report its communicator within %.0f s" % (rank, r, timeout_s))
+            time.sleep(0.005)
+    return all(flags)
 
 
 # ----------------------------------------------------------------------------- helpers
-SCHEDULE_KNOBS = ("SMN_XCD_MAP", "SMN_SUPER", "SMN_SUPER_WIDE", "SMN_SUPER_WIDE_ROWS", "SMN_CHAIN_CUS", "SMN_CHAIN_MIN_N",
-                  "SMN_F0_FIRST_TILES", "SMN_PERSISTENT", "SMN_PANEL_LEAF")
+SCHEDULE_KNOBS = ("SMN_XCD_MAP", "SMN_SUPER", "SMN_SUPER_WIDE_ROWS", "SMN_CHAIN_CUS", "SMN_CHAIN_MIN_N", "SMN_PANEL_LEAF")
 
 
 def pmc_traffic(args, sharded):
@@ -241,7 +376,7 @@ def pmc_traffic(args, sharded):
     changed = [k for k in SCHEDULE_KNOBS if os.environ.get(k) is not None]
     if changed:
         return None, "schedule knobs set (%s): the committed PMC pass is of the default schedule" % ", ".join(changed)
-    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 return json.load(f)["traffic_bytes_per_launch"], "profiles/%s (rocprofv3 --pmc, default schedule)" % name
@@ -298,7 +433,7 @@ class _JsonOut:
         os.write(self.fd, (line + "\n").encode())
 
 
-CATS = ["prep", "build", "recursion", "panel", "strip", "trail", "misc", "comm", "exposed", "build_wait"]
+CATS = ["prep", "build", "recursion", "panel", "strip", "trail", "misc", "comm", "exposed", "stall"]
 
 
 def read_profile(ctx, per_steps):
@@ -574,53 +709,67 @@ def main():
     ctx = L.Context(0 if os.environ.get("SMN_BENCH_SHARE_GPU") == "1" else local_rank)
 
     sharded = world > 1 or args.sharded_path
-    comm_fallback = None
+    comm = {"rccl_ranks": 0, "fallback": None}     # top level of the line: how many ranks the RCCL communicator has, or why none
+    wd = None
     if world > 1:
         # under an external launcher the file name carries the launcher's own run id where it exports one, so that two
-        # runs can never meet in one file
+        # runs can never meet in one file; files older than the launcher itself are ignored (_read_fresh)
         path = args.rendezvous_file or os.path.join(
             tempfile.gettempdir(), "smnngp_uid_%s_%s_%d" % (os.environ.get("MASTER_PORT", "0"),
                                                             os.environ.get("TORCHELASTIC_RUN_ID", "run"), os.getppid()))
+        run_dir = path + ".run"
+        wd = Watchdog(run_dir, rank, world, out_fd)
         err = None
+        wd.phase("rccl id")
         try:
             uid = exchange_rccl_id(L, path, rank)
+            wd.phase("smn_comm_init")
             ctx.call("smn_comm_init", world, rank, uid)
         except Exception as e:   # noqa: BLE001  (no RCCL, no peer access, ...): agree with the other ranks on what to do
             err = "%s: %s" % (type(e).__name__, e)
-        all_ok, rank_dir = agree_on_communicator(path, world, rank, err is None)
+        wd.phase("agree on the communicator")
+        all_ok = agree_on_communicator(run_dir, world, rank, err is None)
         if all_ok:
             sync = RankSync(ctx, world, rank)
+            comm["rccl_ranks"] = world
         else:
-            # No exchange is possible: every rank runs the whole single-GPU step (replicas), timed with the same barrier
-            # and max over ranks through files, and the line says so -- a line beats a dead launcher.
             if err is None:
                 ctx.call("smn_comm_destroy")
-            comm_fallback = err or "another rank could not join the RCCL communicator"
-            sys.stderr.write("bench.py rank %d: no communicator (%s): running %d independent replicas\n" % (rank, comm_fallback, world))
+            comm["fallback"] = err or "another rank could not join the RCCL communicator"
+            if not args.allow_replica_fallback:
+                # a P-GPU line measured on P replicas would read like a flat scaling curve: no line of that kind, a failure
+                if rank == 0:
+                    out_fd.emit(json.dumps({
+                        "metric": "kernel-build + Cholesky wallclock (ms) and GFLOP/s", "value": None, "unit": "GFLOP/s",
+                        "n_gpus": world, "higher_is_better": True, "comm": comm,
+                        "error": "no RCCL communicator over %d ranks (%s); nothing was measured "
+                                 "(--allow-replica-fallback runs independent replicas instead)" % (world, comm["fallback"])}))
+                wd.done()
+                sys.exit(4)
+            # --allow-replica-fallback: every rank runs the whole single-GPU step, timed with the same barrier and max over
+            # ranks through files; the line says "scaling": "replicas"
+            sys.stderr.write("bench.py rank %d: no communicator (%s): running %d independent replicas\n" % (rank, comm["fallback"], world))
             sharded = False
-            sync = FileSync(rank_dir, world, rank)
+            sync = FileSync(run_dir, world, rank)
     else:
         if args.sharded_path:                      # one-rank communicator: the P>1 code path on a one-GPU box
             uid = C.create_string_buffer(128)
             assert L._lib.smn_comm_unique_id(uid) == 0, "RCCL unavailable"
             ctx.call("smn_comm_init", 1, 0, uid)
+            comm["rccl_ranks"] = 1
         sync = RankSync(ctx, world, rank)
+    say = wd.phase if wd is not None else (lambda name: None)
     if world > 1:
-        sync.barrier()                             # every rank has read the id (and every status file): rank 0 removes them
-        if rank == 0:
-            if not args.rendezvous_file:
-                try:
-                    os.unlink(path)
-                except OSError:
-                    pass
-            if comm_fallback is None:              # (the file rendezvous of the fall-back keeps using the directory)
-                shutil.rmtree(rank_dir, ignore_errors=True)
+        say("first barrier")
+        sync.barrier()                             # every rank has read the id and every status file
 
     if args.config == "c3":
         bench_conv(args, out_fd, L, ctx, sync, rank, world)
         if sharded:
             sync.barrier()
             ctx.call("smn_comm_destroy")
+        if wd is not None:
+            wd.done()
         return
 
     rng = np.random.default_rng(0)                 # same seed on every rank: X is replicated
@@ -636,31 +785,37 @@ def main():
             res["v"] = (lp.value, logdet.value, info.value)
         parts = 0
     else:
-        # Balanced symmetric shard (sharding.py, paired layout): rank r builds the lower trapezoids of row blocks r and
-        # 2P-1-r into its own chunk, piece by piece; each finished piece of all ranks is all-gathered and scattered into the
-        # factorisation workspace on the communication stream beside the build of the next one; then every rank factors.
+        # Cyclic column-first shard (sharding.py): rank r builds every lower tile of its tile rows in ONE launch into its own
+        # chunk; the chunk goes out column range by column range (RCCL all-gather + scatter into the factorisation workspace
+        # on side streams) while the factorisation, issued right behind, waits for each range only where it first needs it.
         from smnngp import sharding
-        chunk = sharding.paired_chunk_elems(n, world)
-        mine = ctx.empty((chunk,), np_dtype)
-        stage = ctx.empty((world * chunk,), np_dtype)
-        parts = args.parts or sharding.default_parts(n, world)
+        cols = sharding.default_col_pieces(n, world, max_pieces=args.pieces) if args.pieces else sharding.default_col_pieces(n, world)
+        lay = sharding.col_layout(n, world, cols)
+        parts = len(cols) - 1
+        mine = ctx.empty((lay["elems"],), np_dtype)
+        stage = ctx.empty((world * lay["elems"],), np_dtype)
         backend = sharding.DeviceBackend(ctx)
         spec = (L.NET_MLP, act, nl, 1.0, 1e-8, 1.0)
-        # BASELINE config 5 ("erf NNGP + NTK ... shard + single-GPU Cholesky on assembled kernel"): the build launches are the
-        # joint NNGP + NTK ones and the NTK's pieces ride the same pipeline into a full matrix of the caller's
+        # BASELINE config 5 ("erf NNGP + NTK ... shard + single-GPU Cholesky on assembled kernel"): the build launch is the
+        # joint NNGP + NTK one and the NTK's pieces ride the same streams into a full matrix of the caller's
         ntk = None
         if args.config == "c5" or args.with_ntk:
-            ntk_arrays = (ctx.empty((chunk,), np_dtype), ctx.empty((world * chunk,), np_dtype), ctx.empty((n, n), np_dtype))
+            ntk_arrays = (ctx.empty((lay["elems"],), np_dtype), ctx.empty((world * lay["elems"],), np_dtype), ctx.empty((n, n), np_dtype))
             res["ntk_arrays"] = ntk_arrays                  # owners stay alive for the run
             ntk = (ntk_arrays[0].ptr, ntk_arrays[1].ptr, ntk_arrays[2].ptr, n)
+        res["k"] = 0
 
         def step():
-            v = sharding.lml_sharded_pipelined(backend, code, spec, x.ptr, n, d, d, y.ptr, rank, world, mine.ptr, stage.ptr,
-                                               eps, 0.0, 1.0, parts=parts, ntk=ntk)
+            res["k"] += 1
+            k = res["k"]
+            v = sharding.lml_sharded_cols(backend, code, spec, x.ptr, n, d, d, y.ptr, rank, world, mine.ptr, stage.ptr,
+                                          eps, 0.0, 1.0, cols=cols, ntk=ntk, progress=lambda ph: say("step %d: %s" % (k, ph)))
             res["v"] = (v[0], v[2], v[3])
 
+    say("warm-up")
     for _ in range(args.warmup):
         step()
+    say("barrier before the timed region")
     sync.barrier()
     # Timed region: hipEvent pairs around the launches of the DOMINANT kernel only (category 5, the Cholesky trailing
     # update: 79 launches per step).  Pairs around all ~280 launches of a step cost ~2 ms of queue time per step
@@ -669,8 +824,10 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    say("barrier after the timed region")
     sync.barrier()
     dt = time.perf_counter() - t0
+    say("detail pass")
     ms, cnt = C.c_double(), C.c_int()
     ctx.call("smn_profile_read", 5, C.byref(ms), C.byref(cnt))
     trail_timed = (ms.value / max(args.steps, 1), cnt.value // max(args.steps, 1))
@@ -703,10 +860,7 @@ def main():
             build_tiles = t * (t + 1) // 2
         else:
             from smnngp import sharding as S_
-            build_tiles = 0                                               # lower tiles rank 0's two blocks execute
-            for b in S_.paired_blocks(world, 0):
-                rb_, re_ = S_.block_range(n, world, b)
-                build_tiles += sum(tt + 1 for tt in range(rb_ // TILE, -(-re_ // TILE)))
+            build_tiles = sum(tt + 1 for tt in S_.rank_tile_rows(n, world, 0))   # lower tiles rank 0's tile rows hold
         build_fl = build_tiles * TILE * TILE * 2.0 * kp
         trail_ms = per["trail"][0]
         roof = {
@@ -730,9 +884,10 @@ def main():
         # understates the kernel.  Two more readings of the same kernel:
         min_n_env = os.environ.get("SMN_CHAIN_MIN_N")
         lookahead = n_total >= int(min_n_env or "8192") and int(os.environ.get("SMN_CHAIN_CUS", "32")) > 0
-        # (a pipelined sharded build on the two build streams: its launches overlap, the wall time is `build_wait`)
-        build_wall_ms = per["build_wait"][0] if per["build_wait"][0] > 0.0 else per["build"][0]
-        chol_wall_ms = ms_per_step - build_wall_ms - per["prep"][0] - (0.0 if per["build_wait"][0] > 0.0 else per["misc"][0]) - per["exposed"][0]
+        # (sharded: the all-gathers and scatters ride under the factorisation on side streams; what the main stream waited for
+        # before its first panel is `exposed` and is not the factorisation's time)
+        build_wall_ms = per["build"][0]
+        chol_wall_ms = ms_per_step - build_wall_ms - per["prep"][0] - (0.0 if sharded else per["misc"][0]) - per["exposed"][0]
         roof["cholesky_wall_ms"] = chol_wall_ms
         # every MFMA flop of the factorisation (trailing + strip updates) over its wall time, panel chain included
         roof["cholesky_mfma_frac"] = (trail_fl + strip_fl) / (chol_wall_ms * 1e-3) / 1e12 / peak
@@ -780,14 +935,14 @@ def main():
             "metric": "kernel-build + Cholesky wallclock (ms) and GFLOP/s at N=%d, %d-layer %s NNGP" % (n, nl, args.act),
             "value": flops_counted / (ms_per_step * 1e-3) / 1e9, "unit": "GFLOP/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": args.dtype, "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if (sharded or world == 1) else "replicas", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic", "comm": comm,
             "config": {"workload": "%s: SPR.loss = NNGP kernel build + jittered Cholesky + Gaussian LML, N=%d d=%d L=%d %s"
                                    % (args.config.upper(), n, d, nl, args.act),
                        "N": n, "d": d, "layers": nl, "act": args.act, "w_std": 1.0, "b_std": 1e-8, "last_w_std": 1.0,
                        "eps_abs": eps, "flops_counted": flops_counted,
-                       "parallelism": ("single GPU" if world == 1 else "%d independent replicas (no RCCL communicator: %s)" % (world, comm_fallback)) if not sharded else
-                       "paired lower-block row shards x%d, exchange in %d pieces pipelined behind the build (RCCL all-gather per piece), replicated Cholesky" % (world, parts)},
+                       "parallelism": ("single GPU" if world == 1 else "%d independent replicas (--allow-replica-fallback; no RCCL communicator: %s)" % (world, comm["fallback"])) if not sharded else
+                       "cyclic tile-row shards x%d (one build launch per rank), column-first exchange in %d ranges (RCCL all-gather + scatter per range on side streams, consumed by the factorisation range by range), replicated Cholesky" % (world, parts)},
             "executed_tflops": executed / (ms_per_step * 1e-3) / 1e12,
             "executed_note": "MFMA flops actually issued per step (lower-triangle Gram tiles + whole update tiles; rank 0's share of the build when sharded) / step time; `value` counts 2N^2 d + N^3/3",
             "phases_ms": {k: round(v[0], 4) for k, v in per.items()},
@@ -796,21 +951,23 @@ def main():
             "roofline": roof,
         }
         if sharded:
-            # The north-star's "kernel-build speed-up at N GPUs", stated INCLUDING the exchange: this rank's build launches,
-            # the all-gathers (they run beside the build), the scatter into the workspace, and what of all that the main
-            # stream had to wait for after its last build launch (`exposed`).  The one-GPU lower build of the same shape for
-            # the ratio is `phases_ms.build` of the N=1 line.
-            # With a multi-rank communicator (or SMN_COMM_CUS_FORCE=1) the pieces' builds run on two CU-masked build streams and
-            # overlap each other's tails: their launches summed (`kernel_build_ms`) double-count, the wall time is what the
-            # main stream waited for them (`build_wait`; 0 when the builds ran on the main stream itself).
-            build_wall = build_wall_ms
+            # The north-star's "kernel-build speed-up at N GPUs", stated with and without the exchange.  The rank's build is ONE
+            # launch on every CU (`kernel_build_ms`).  The all-gathers (`exchange_ms`, summed over the column ranges) and the
+            # scatters (`scatter_ms`) run on side streams UNDER the factorisation; what the main stream waited for between the
+            # end of its build and its first panel -- the first column range's gather + scatter -- is `exchange_exposed_ms`, and
+            # any later wait of the factorisation for a range that had not landed yet is `exchange_stall_ms` (0 when the first
+            # panel chain covers the rest of the exchange).  The whole step is Amdahl-bound: every rank repeats the
+            # factorisation (north_star: "single-GPU Cholesky on the assembled kernel").
             out["kernel_build_ms"] = round(per["build"][0], 4)
-            out["kernel_build_wall_ms"] = round(build_wall, 4)
             out["exchange_ms"] = round(per["comm"][0], 4)
             out["scatter_ms"] = round(per["misc"][0], 4)
             out["exchange_exposed_ms"] = round(per["exposed"][0], 4)
-            out["build_plus_assemble_ms"] = round(build_wall + per["prep"][0] + per["exposed"][0], 4)
-            out["exchange_parts"] = parts
+            out["exchange_stall_ms"] = round(per["stall"][0], 4)
+            out["build_plus_exposed_assembly_ms"] = round(per["build"][0] + per["prep"][0] + per["exposed"][0], 4)
+            out["exchange_ranges"] = parts
+            out["exchange_bytes_in_per_rank"] = int((world - 1) * lay["elems"] * np.dtype(np_dtype).itemsize * (2 if ntk is not None else 1))
+            out["whole_step_note"] = ("strong scaling of the kernel build only: the factorisation (%.1f ms of the step) is replicated on every rank, "
+                                      "so ms_per_step is Amdahl-bound" % chol_wall_ms)
             # the same shape's fused lower build on ONE GPU, measured here and now on this rank (one un-sharded step), for the ratio
             try:
                 ctx.call("smn_profile_enable", 2 << 1)
@@ -822,8 +979,8 @@ def main():
                 ctx.call("smn_profile_enable", 0)
                 one = ms1.value / max(cnt1.value, 1)
                 out["one_gpu_build_ms"] = round(one, 4)
-                out["build_speedup_launches_only"] = round(one / max(build_wall_ms, 1e-9), 3)
-                out["build_plus_assemble_speedup"] = round((one + per["prep"][0]) / max(out["build_plus_assemble_ms"], 1e-9), 3)
+                out["build_only_speedup"] = round(one / max(per["build"][0], 1e-9), 3)
+                out["build_plus_exposed_assembly_speedup"] = round((one + per["prep"][0]) / max(out["build_plus_exposed_assembly_ms"], 1e-9), 3)
             except Exception as e:
                 out["one_gpu_build_error"] = str(e)
         # stand-alone recursion (a3): HBM roofline probe on a stored K0, outside the timed region
@@ -871,8 +1028,11 @@ def main():
             out["cpu_baseline"] = None
         out_fd.emit(json.dumps(out))
     if sharded:
+        say("final barrier")
         sync.barrier()
         ctx.call("smn_comm_destroy")
+    if wd is not None:
+        wd.done()
 
 
 if __name__ == "__main__":

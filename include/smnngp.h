@@ -62,8 +62,8 @@ int smn_timer_stop_ms(smn_ctx* ctx, double* ms);           /* synchronises */
 /* per-kernel timing: while enabled kernel launches are bracketed by a hipEvent pair on their own
  * stream.  category: 0 prep (pad/tables), 1 fused Gram+recursion build, 2 stand-alone recursion,
  * 3 Cholesky panel, 4 Cholesky strip update, 5 Cholesky trailing update, 6 other (scatter of gathered blocks),
- * 7 all-gathers, 8 the wait of the main stream for the last piece of a pipelined exchange (its exposed part),
- * 9 the wait of the main stream for the builds of a pipelined exchange's pieces (they run on two build streams: their wall time).
+ * 7 all-gathers, 8 the wait of the main stream for the FIRST piece of a column-first exchange (its exposed part),
+ * 9 later waits of the factorisation for pieces the first panel chain did not cover (stalls).
  * on: 0 off; 1 every category; (2 << c) only category c (values add up to a mask).  An event pair
  * costs a few microseconds of queue time per launch, so timing ONE category perturbs a step far less
  * than timing all ~280 launches of it. */
@@ -252,45 +252,45 @@ int smn_lml_from_blocks(smn_ctx* ctx, int dtype, const void* stage_d, int64_t n,
 /* nranks / rank of the context's communicator (1 / 0 without one). */
 int smn_comm_info(smn_ctx* ctx, int* nranks, int* rank);
 
-/* ---- pipelined exchange: the all-gather rides behind the build, piece by piece ----
- * A rank's chunk (block_rows^2 (2 nranks + 1) elements, low block first) is cut into `parts` equal pieces (element
- * ranges; parts must divide the chunk into multiples of 4 elements).  The rank builds the tile rows that complete
- * piece g (host side: sharding.py part_tile_rows) into its own contiguous chunk `mine_d`, piece g of all ranks is
- * gathered into stage_d laid out [parts][nranks][piece] and scattered into K while piece g+1 is being built.
- *   smn_kernel_mlp_shard_rows   smn_kernel_mlp_shard restricted to tile rows [lo_t0,lo_t1) of the low block and
- *                               [hi_t0,hi_t1) of the high block (128-row tiles from the block's first row);
- *                               reuse_operand != 0 skips the padding of x (same x as the previous shard call)
- *   smn_allgather_part          piece `part`: mine_d + part*piece  ->  stage_d + part*nranks*piece, context's stream
- *   smn_unpack_lower_parts      pieces [part_begin, part_end) of stage_d -> lower triangle of k_d [n,n], context's stream
- *   smn_shard_begin             the factorisation workspace of smn_lml_from_shards, made ready before the first piece
- *   smn_shard_exchange_part     all-gather + scatter of one piece into that workspace on the context's COMMUNICATION
- *                               stream, ordered after everything issued so far on its main stream; returns at once.
- *                               nranks must equal the communicator's size (SMN_ECOMM otherwise: a world > 1 call on a
- *                               context without a communicator would gather nothing)
- *   smn_lml_from_shards         waits for the last piece, then factorisation + head: same outputs as smn_lml */
-int smn_kernel_mlp_shard_rows(smn_ctx* ctx, int dtype, int net, int act, int num_hiddens,
+/* ---- column-first exchange: the factorisation starts on the columns that have arrived ----
+ * Cyclic layout (host side: sharding.py; nothing in the reference to mirror, run.py:17 only masks devices).  The 128-row
+ * tile rows are dealt to the ranks in boustrophedon order with period 2*nranks: group j = tile rows [j P, (j+1) P), rank r
+ * owns t_j(r) = j P + (j even ? r : P-1-r).  Every rank builds the same number of lower tiles and every aligned group of P
+ * tile rows holds one tile row per rank, so any tile-COLUMN range [c0, c1) with c0 a multiple of P is an equal-count
+ * all-gather: ceil((T - c0) / P) strips of 128 x (c1-c0)*128 elements per rank (T = ceil(n / 128)).  piece_cols[0..npieces]
+ * are those boundaries (0 = piece_cols[0] < ... < piece_cols[npieces] = T, at most 16 pieces); a rank's chunk holds its
+ * pieces one after the other, the staging buffer piece g of all ranks at nranks * (offset of piece g).
+ *   smn_shard_begin            the factorisation workspace of smn_lml_from_shards, made ready before the first piece lands;
+ *                              eps_abs is the absolute jitter (spax/models.py:96), added to the diagonal as it is scattered
+ *   smn_kernel_mlp_shard_cols  the rank's whole share of the build in ONE launch, into its chunk nngp_chunk_d / ntk_chunk_d
+ *   smn_shard_exchange_cols    piece `piece`: RCCL all-gather on the context's communication stream (ordered after everything
+ *                              issued so far on its main stream), scatter into the workspace on a third stream; returns at
+ *                              once.  nranks must equal the communicator's size (SMN_ECOMM otherwise)
+ *   smn_shard_exchange_cols_to the same, scattered into k_d [n,n] ld=ldk (lower triangle by 128-column tiles): the NTK of a
+ *                              joint NNGP + NTK shard (BASELINE config 5; the reference's only use: sample.ipynb cells 194-195)
+ *   smn_shard_scatter_cols     the scatter half alone, from a staging buffer the caller filled on the main stream (k_d NULL:
+ *                              into the workspace, as smn_shard_exchange_cols does)
+ *   smn_shard_wait             the main stream waits for every piece issued so far
+ *   smn_lml_from_shards        factorisation + head, same outputs as smn_lml.  The factorisation waits for the pieces one by
+ *                              one as it reaches their columns: only the first piece is exposed, the rest of the exchange
+ *                              rides under the first super-panel's panel chain
+ *   smn_debug_delay            test hook: holds stream 0 (main) / 1 (communication) / 2 (scatter) for usec microseconds */
+int smn_shard_begin(smn_ctx* ctx, int dtype, int64_t n, double eps_abs);
+int smn_kernel_mlp_shard_cols(smn_ctx* ctx, int dtype, int net, int act, int num_hiddens,
                               double w_std, double b_std, double last_w_std,
                               const void* x_d, int64_t n, int64_t ldx, int64_t d,
-                              int nranks, int rank, int64_t block_rows,
-                              int64_t lo_t0, int64_t lo_t1, int64_t hi_t0, int64_t hi_t1, int reuse_operand,
+                              int nranks, int rank, int npieces, const int64_t* piece_cols,
                               int get_mask, void* nngp_chunk_d, void* ntk_chunk_d);
-int smn_allgather_part(smn_ctx* ctx, int dtype, const void* mine_d, void* stage_d, int64_t chunk_elems,
-                       int parts, int part);
-int smn_unpack_lower_parts(smn_ctx* ctx, int dtype, const void* stage_d, int64_t n, int nranks,
-                           int64_t block_rows, int parts, int part_begin, int part_end, void* k_d, int64_t ldk);
-int smn_shard_begin(smn_ctx* ctx, int dtype, int64_t n);
-int smn_shard_exchange_part(smn_ctx* ctx, int dtype, const void* mine_d, void* stage_d, int64_t n, int nranks,
-                            int64_t block_rows, int parts, int part);
-int smn_lml_from_shards(smn_ctx* ctx, int dtype, int64_t n, const void* y_d, double eps_abs, double df, double scale,
-                        double* logpdf_h, double* quad_h, double* logdet_h, int* info_h);
-/* smn_shard_exchange_part with the scatter target named by the caller: k_d [n,n] ld=ldk (lower triangle by 128-column
- * tiles) instead of the factorisation workspace -- the NTK of a joint NNGP + NTK shard (get_mask = 3 in
- * smn_kernel_mlp_shard_rows; BASELINE config 5, the reference's only use: sample.ipynb cells 194-195).  Same communication
- * stream, same ordering.  smn_shard_wait makes the context's main stream wait for every piece issued so far
- * (smn_lml_from_shards does so by itself). */
-int smn_shard_exchange_part_to(smn_ctx* ctx, int dtype, const void* mine_d, void* stage_d, int64_t n, int nranks,
-                               int64_t block_rows, int parts, int part, void* k_d, int64_t ldk);
+int smn_shard_exchange_cols(smn_ctx* ctx, int dtype, const void* mine_d, void* stage_d, int64_t n, int nranks,
+                            int npieces, const int64_t* piece_cols, int piece);
+int smn_shard_exchange_cols_to(smn_ctx* ctx, int dtype, const void* mine_d, void* stage_d, int64_t n, int nranks,
+                               int npieces, const int64_t* piece_cols, int piece, void* k_d, int64_t ldk);
+int smn_shard_scatter_cols(smn_ctx* ctx, int dtype, const void* stage_d, int64_t n, int nranks, int npieces,
+                           const int64_t* piece_cols, int piece, void* k_d, int64_t ldk);
 int smn_shard_wait(smn_ctx* ctx);
+int smn_lml_from_shards(smn_ctx* ctx, int dtype, int64_t n, const void* y_d, double df, double scale,
+                        double* logpdf_h, double* quad_h, double* logdet_h, int* info_h);
+int smn_debug_delay(smn_ctx* ctx, int stream_id, int64_t usec);
 
 #ifdef __cplusplus
 }

@@ -40,6 +40,7 @@ _lib = _load()
 
 _vp, _i, _i64, _d, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_double, C.c_size_t
 _pi, _pd, _pvp = C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_void_p)
+_pi64 = C.POINTER(C.c_int64)
 
 # name -> argtypes  (restype is always int).  Mirrors include/smnngp.h one to one.
 PROTOTYPES = {
@@ -87,15 +88,14 @@ PROTOTYPES = {
     "smn_unpack_lower_blocks": [_vp, _i, _vp, _i64, _i, _i64, _vp, _i64],
     "smn_lml_from_blocks": [_vp, _i, _vp, _i64, _i, _i64, _vp, _d, _d, _d, _pd, _pd, _pd, _pi],
     "smn_comm_info": [_vp, _pi, _pi],
-    "smn_kernel_mlp_shard_rows": [_vp, _i, _i, _i, _i, _d, _d, _d, _vp, _i64, _i64, _i64, _i, _i, _i64, _i64, _i64, _i64, _i64,
-                                  _i, _i, _vp, _vp],
-    "smn_allgather_part": [_vp, _i, _vp, _vp, _i64, _i, _i],
-    "smn_shard_exchange_part_to": [_vp, _i, _vp, _vp, _i64, _i, _i64, _i, _i, _vp, _i64],
+    "smn_shard_begin": [_vp, _i, _i64, _d],
+    "smn_kernel_mlp_shard_cols": [_vp, _i, _i, _i, _i, _d, _d, _d, _vp, _i64, _i64, _i64, _i, _i, _i, _pi64, _i, _vp, _vp],
+    "smn_shard_exchange_cols": [_vp, _i, _vp, _vp, _i64, _i, _i, _pi64, _i],
+    "smn_shard_exchange_cols_to": [_vp, _i, _vp, _vp, _i64, _i, _i, _pi64, _i, _vp, _i64],
+    "smn_shard_scatter_cols": [_vp, _i, _vp, _i64, _i, _i, _pi64, _i, _vp, _i64],
     "smn_shard_wait": [_vp],
-    "smn_unpack_lower_parts": [_vp, _i, _vp, _i64, _i, _i64, _i, _i, _i, _vp, _i64],
-    "smn_shard_begin": [_vp, _i, _i64],
-    "smn_shard_exchange_part": [_vp, _i, _vp, _vp, _i64, _i, _i64, _i, _i],
-    "smn_lml_from_shards": [_vp, _i, _i64, _vp, _d, _d, _d, _pd, _pd, _pd, _pi],
+    "smn_lml_from_shards": [_vp, _i, _i64, _vp, _d, _d, _pd, _pd, _pd, _pi],
+    "smn_debug_delay": [_vp, _i, _i64],
 }
 for _name, _args in PROTOTYPES.items():
     _fn = getattr(_lib, _name)          # AttributeError here == a symbol the header declares is missing

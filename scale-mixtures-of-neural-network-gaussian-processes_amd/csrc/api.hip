@@ -15,17 +15,17 @@ int smn_allow_lds(smn_ctx* ctx, const void* kernel, size_t lds) {
 static int sync_side_streams(smn_ctx* ctx) {
   if (ctx->stream_comm) SMN_HIP(ctx, hipStreamSynchronize(ctx->stream_comm));
   if (ctx->stream_scatter) SMN_HIP(ctx, hipStreamSynchronize(ctx->stream_scatter));
-  if (ctx->stream_build) SMN_HIP(ctx, hipStreamSynchronize(ctx->stream_build));
-  for (hipStream_t s : ctx->stream_bx)
-    if (s) SMN_HIP(ctx, hipStreamSynchronize(s));
+  if (ctx->stream_bulk) SMN_HIP(ctx, hipStreamSynchronize(ctx->stream_bulk));
   return SMN_OK;
 }
 
 int smn_workspace(smn_ctx* ctx, int slot, size_t bytes, void** out) {
   if (slot < 0 || slot >= smn_ctx::kSlots) return smn_fail(ctx, SMN_EINVAL, "bad workspace slot");
-  if (slot == 0) ctx->op_x = nullptr;   // whoever asks for slot 0 is about to overwrite the padded operand
   if (ctx->ws_bytes[slot] < bytes) {
-    if (slot == 2) ctx->shard_a = nullptr;   // a pipelined exchange in flight must not scatter into the freed buffer
+    if (slot == 2) {   // a column-first exchange in flight must not scatter into the freed buffer
+      ctx->shard_a = nullptr;
+      ctx->arrivals.clear();
+    }
     if (ctx->ws[slot]) {
       SMN_TRY(sync_side_streams(ctx));
       SMN_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -270,14 +270,10 @@ extern "C" int smn_ctx_create(int device_id, smn_ctx** out) {
   if (hipSetDevice(device_id) != hipSuccess) return SMN_EHIP;
   smn_ctx* c = new smn_ctx();
   c->device = device_id;
+  // Run-time knobs (six; everything else the earlier rounds swept is a constant now: profiles/r02_knob_sweep_final.txt):
+  //   SMN_XCD_MAP, SMN_SUPER, SMN_SUPER_WIDE_ROWS, SMN_CHAIN_CUS, SMN_CHAIN_MIN_N, SMN_PANEL_LEAF
   if (const char* e = getenv("SMN_XCD_MAP")) c->xcd_map = e[0] == '1';
-  if (const char* e = getenv("SMN_PERSISTENT")) c->persistent_trail = e[0] != '0';
-  if (const char* e = getenv("SMN_REC_SYM")) c->rec_sym = e[0] != '0';
-  if (const char* e = getenv("SMN_CNN_TILED")) c->cnn_tiled = atoi(e);
-  if (const char* e = getenv("SMN_CNN_FAST32")) c->cnn_fast32 = atoi(e);
-  if (const char* e = getenv("SMN_CNN_PATCH44")) c->cnn_patch44 = e[0] != '0';
   if (const char* e = getenv("SMN_SUPER")) c->super_panel = atol(e);
-  if (const char* e = getenv("SMN_SUPER_WIDE")) c->super_panel_wide = atol(e);
   if (const char* e = getenv("SMN_SUPER_WIDE_ROWS")) c->super_wide_rows = atol(e);
   if (const char* e = getenv("SMN_PANEL_LEAF")) c->panel_leaf = e[0] != '0';
   {
@@ -298,22 +294,8 @@ extern "C" int smn_ctx_create(int device_id, smn_ctx** out) {
   const bool main_ok = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_hi) == hipSuccess;
   if (const char* e = getenv("SMN_CHAIN_CUS")) c->chain_cus = atoi(e);
   if (const char* e = getenv("SMN_CHAIN_MIN_N")) c->chain_min_n = atol(e);
-  if (const char* e = getenv("SMN_F0_FIRST_TILES")) c->f0_first_tiles = atol(e);
   if (c->chain_cus > 0 && c->chain_cus < c->num_cu) {
     if (!masked_stream(&c->stream_bulk, c->chain_cus, c->num_cu)) c->stream_bulk = nullptr;   // no look-ahead then
-  }
-  if (const char* e = getenv("SMN_COMM_CUS")) c->comm_cus = atoi(e);
-  if (const char* e = getenv("SMN_COMM_CUS_FORCE")) c->comm_cus_force = e[0] == '1';
-  if (const char* e = getenv("SMN_SHARD_HALF_TILES")) c->shard_half_tiles_max = atol(e);
-  if (c->comm_cus > 0 && c->comm_cus < c->num_cu) {
-    if (!masked_stream(&c->stream_build, c->comm_cus, c->num_cu)) c->stream_build = nullptr;  // builds stay on the main stream then
-    int want = 2;   // two is the measured best: a third and fourth masked queue slow even a single launch down (r03_shard_pieces_probe.json)
-    if (const char* e = getenv("SMN_BUILD_STREAMS")) want = atoi(e);
-    if (want > smn_ctx::kBuildStreams) want = smn_ctx::kBuildStreams;
-    for (int i = 0; c->stream_build && i < want - 1; ++i) {   // (pieces stay serial if none comes up)
-      if (!masked_stream(&c->stream_bx[i], c->comm_cus, c->num_cu)) { c->stream_bx[i] = nullptr; break; }
-      c->n_build_streams = i + 2;
-    }
   }
   bool ok = main_ok &&
             hipEventCreateWithFlags(&c->ev_a, hipEventDisableTiming) == hipSuccess &&
@@ -322,13 +304,6 @@ extern "C" int smn_ctx_create(int device_id, smn_ctx** out) {
             hipEventCreateWithFlags(&c->ev_c1, hipEventDisableTiming) == hipSuccess &&
             hipStreamCreateWithPriority(&c->stream_comm, hipStreamNonBlocking, prio_hi) == hipSuccess &&
             hipStreamCreateWithPriority(&c->stream_scatter, hipStreamNonBlocking, prio_hi) == hipSuccess &&
-            hipEventCreateWithFlags(&c->ev_g, hipEventDisableTiming) == hipSuccess &&
-            hipEventCreateWithFlags(&c->ev_b0, hipEventDisableTiming) == hipSuccess &&
-            hipEventCreateWithFlags(&c->ev_b1, hipEventDisableTiming) == hipSuccess &&
-            hipEventCreateWithFlags(&c->ev_bd[0], hipEventDisableTiming) == hipSuccess &&
-            hipEventCreateWithFlags(&c->ev_bd[1], hipEventDisableTiming) == hipSuccess &&
-            hipEventCreateWithFlags(&c->ev_bd[2], hipEventDisableTiming) == hipSuccess &&
-            hipEventCreateWithFlags(&c->ev_bd[3], hipEventDisableTiming) == hipSuccess &&
             hipEventCreate(&c->ev_t0) == hipSuccess && hipEventCreate(&c->ev_t1) == hipSuccess &&
             hipMalloc(reinterpret_cast<void**>(&c->d_scal), 64 * sizeof(double)) == hipSuccess &&
             hipMalloc(reinterpret_cast<void**>(&c->d_info), 16 * sizeof(int)) == hipSuccess &&
@@ -346,9 +321,6 @@ extern "C" int smn_ctx_destroy(smn_ctx* c) {
   if (!c) return SMN_OK;
   (void)hipSetDevice(c->device);
   if (c->stream_bulk) (void)hipStreamSynchronize(c->stream_bulk);
-  if (c->stream_build) (void)hipStreamSynchronize(c->stream_build);
-  for (hipStream_t s : c->stream_bx)
-    if (s) (void)hipStreamSynchronize(s);
   if (c->stream_comm) (void)hipStreamSynchronize(c->stream_comm);
   if (c->stream_scatter) (void)hipStreamSynchronize(c->stream_scatter);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
@@ -365,14 +337,7 @@ extern "C" int smn_ctx_destroy(smn_ctx* c) {
   if (c->ev_c1) (void)hipEventDestroy(c->ev_c1);
   if (c->stream_comm) (void)hipStreamDestroy(c->stream_comm);
   if (c->stream_scatter) (void)hipStreamDestroy(c->stream_scatter);
-  if (c->ev_g) (void)hipEventDestroy(c->ev_g);
-  if (c->stream_build) (void)hipStreamDestroy(c->stream_build);
-  for (hipStream_t s : c->stream_bx)
-    if (s) (void)hipStreamDestroy(s);
-  if (c->ev_b0) (void)hipEventDestroy(c->ev_b0);
-  if (c->ev_b1) (void)hipEventDestroy(c->ev_b1);
-  for (hipEvent_t e : c->ev_bd)
-    if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
   if (c->ev_t0) (void)hipEventDestroy(c->ev_t0);
   if (c->ev_t1) (void)hipEventDestroy(c->ev_t1);
   if (c->stream) (void)hipStreamDestroy(c->stream);

@@ -42,6 +42,7 @@
 #include <climits>
 #include <cstdlib>
 #include <type_traits>
+#include <vector>
 
 #include "gemm_nt.hpp"
 #include "internal.hpp"
@@ -56,6 +57,8 @@ constexpr int kQuarterTileMax = 256;   // update launches of at most this many 1
 constexpr int kHalfTileMax = 384;      // ... and of at most this many, 64-row tiles
 constexpr int kPersistMaxK = 512;      // largest K the persistent trailing kernel takes
 constexpr int kPanelSmallRows = 4096;  // f32 panels with at most this many rows below use 64-row workgroups
+constexpr int64_t kSuperWide = 2048;   // super-panel width while at least ctx->super_wide_rows rows are left (profiles/r02_wide_super_panel_sweep.txt)
+constexpr int64_t kF0FirstTiles = 2000;   // F1 launches of at most this many tiles start behind F0, not beside it (profiles/r02_f0_first_ab.txt)
 
 template <typename T>
 struct PanelCfg;
@@ -987,7 +990,7 @@ int launch_update(smn_ctx* ctx, hipStream_t st, T* a, int64_t lda, int64_t r0, i
   if constexpr (sizeof(T) == 4) {
     // CUs this stream may use: the bulk stream of the look-ahead is masked off the chain's CUs
     const int cus = (st == ctx->stream_bulk && st != nullptr) ? ctx->num_cu - ctx->chain_cus : ctx->num_cu;
-    if (tag == 1 && lower && !u.use_map && ctx->persistent_trail && nt > 2 * cus && K <= kPersistMaxK) {
+    if (tag == 1 && lower && !u.use_map && nt > 2 * cus && K <= kPersistMaxK) {
       // persistent walk over the lower tiles, two workgroups per CU
       const size_t plds = TileNT<T, kTile, kTile, 2>::LDS_BYTES;
       ProfScope ps(ctx, PROF_TRAIL, st);
@@ -1139,7 +1142,7 @@ int cholesky_t(smn_ctx* ctx, T* a, int64_t n_total, int64_t n_factor, int64_t ld
   constexpr int64_t W = 2 * PB;
   int64_t S = ctx->super_panel / W * W;
   if (S < W) S = W;
-  int64_t Swide = ctx->super_panel_wide / W * W;
+  int64_t Swide = kSuperWide;
   if (Swide < S) Swide = S;
   hipStream_t sb = (n_total >= ctx->chain_min_n && ctx->stream_bulk) ? ctx->stream_bulk : nullptr;
   bool bulk_busy = false;
@@ -1147,6 +1150,34 @@ int cholesky_t(smn_ctx* ctx, T* a, int64_t n_total, int64_t n_factor, int64_t ld
   auto hip_ok = [&](hipError_t e) {
     if (e != hipSuccess && rc == SMN_OK)
       rc = smn_fail(ctx, SMN_EHIP, "cholesky: %s", hipGetErrorString(e));
+  };
+  // Column-first multi-GPU exchange (heads.hip smn_lml_from_shards): the kernel's columns land in this workspace piece by
+  // piece while the factorisation is already being issued.  A stream about to touch columns [.., col_hi) waits for the
+  // pieces that hold them, once each: the panel chain of a super-panel for its own columns, F0 for the next super-panel's,
+  // the bulk update F1 for everything.  The first wait (super-panel 0) is what of the exchange is exposed; later ones are
+  // stalls the first panel chain did not cover (separate profile categories).
+  const bool arriving = ctx->consume_arrivals && !ctx->arrivals.empty();
+  std::vector<char> seen_main, seen_bulk;
+  if (arriving) {
+    seen_main.assign(ctx->arrivals.size(), 0);
+    seen_bulk.assign(ctx->arrivals.size(), 0);
+  }
+  bool first_need = true;
+  auto need_columns = [&](hipStream_t s, int64_t col_hi) -> int {
+    if (!arriving) return SMN_OK;
+    std::vector<char>& seen = (s == st) ? seen_main : seen_bulk;
+    bool any = false;
+    for (size_t i = 0; i < ctx->arrivals.size(); ++i)
+      if (!seen[i] && ctx->arrivals[i].col_begin < col_hi) any = true;
+    if (!any) return SMN_OK;
+    ProfScope ps(ctx, first_need ? PROF_EXPOSED : PROF_STALL, s);
+    first_need = false;
+    for (size_t i = 0; i < ctx->arrivals.size(); ++i)
+      if (!seen[i] && ctx->arrivals[i].col_begin < col_hi) {
+        SMN_HIP(ctx, hipStreamWaitEvent(s, ctx->arrivals[i].ev, 0));
+        seen[i] = 1;
+      }
+    return SMN_OK;
   };
   auto body = [&]() -> int {
     // Super-panels are wider while many rows are left (the update-bound phase: a K = 2048 far update runs closer to the
@@ -1156,6 +1187,7 @@ int cholesky_t(smn_ctx* ctx, T* a, int64_t n_total, int64_t n_factor, int64_t ld
       const int64_t Sc = width(s0);
       const int64_t s_end = (n_factor - s0 < Sc) ? n_factor : s0 + Sc;
       s_stop = s_end;
+      SMN_TRY(need_columns(st, s_end));
       for (int64_t j0 = s0; j0 < s_end; j0 += W) {
         const int64_t w = (s_end - j0 < W) ? s_end - j0 : W;
         for (int64_t js = j0; js < j0 + w; js += PB) {
@@ -1170,6 +1202,7 @@ int cholesky_t(smn_ctx* ctx, T* a, int64_t n_total, int64_t n_factor, int64_t ld
       if (s_end >= n_total) break;
       const int64_t K = s_end - s0;
       if (!sb) {   // far update, one launch
+        SMN_TRY(need_columns(st, n_total));
         const int64_t tm = (n_total - s_end) / kTile;
         SMN_TRY(launch_update<T>(ctx, st, a, lda, s_end, s_end, s0, K, tm, tm, 1));
         continue;
@@ -1179,12 +1212,13 @@ int cholesky_t(smn_ctx* ctx, T* a, int64_t n_total, int64_t n_factor, int64_t ld
       // Once F1 is small (the chain-bound tail) it starts BEHIND F0 instead of beside it: F0 is on the chain's critical path
       // and, sharing the chip with an F1 that nobody waits for, takes three times as long (profiles/r02_tail_chain_timeline.txt).
       const int64_t tm1 = n_total > s_next ? (n_total - s_next) / kTile : 0;
-      const bool f0_first = tm1 * (tm1 + 1) / 2 <= ctx->f0_first_tiles;
+      const bool f0_first = tm1 * (tm1 + 1) / 2 <= kF0FirstTiles;
       if (!f0_first) {
         SMN_HIP(ctx, hipEventRecord(ctx->ev_a, st));
         SMN_HIP(ctx, hipStreamWaitEvent(sb, ctx->ev_a, 0));
       }
       if (bulk_busy) SMN_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_b, 0));
+      if (s_next > s_end) SMN_TRY(need_columns(st, s_next));
       if (s_next > s_end)   // F0
         SMN_TRY(launch_update<T>(ctx, st, a, lda, s_end, s_end, s0, K, (n_total - s_end) / kTile, (s_next - s_end) / kTile, 2));
       if (f0_first) {
@@ -1194,6 +1228,7 @@ int cholesky_t(smn_ctx* ctx, T* a, int64_t n_total, int64_t n_factor, int64_t ld
       if (n_total > s_next) {   // F1
         const int64_t tm = (n_total - s_next) / kTile;
         bulk_busy = true;       // set first: an error below must still join the bulk stream
+        SMN_TRY(need_columns(sb, n_total));
         SMN_TRY(launch_update<T>(ctx, sb, a, lda, s_next, s_next, s0, K, tm, tm, 1));
         SMN_HIP(ctx, hipEventRecord(ctx->ev_b, sb));
       }
@@ -1201,6 +1236,11 @@ int cholesky_t(smn_ctx* ctx, T* a, int64_t n_total, int64_t n_factor, int64_t ld
     return SMN_OK;
   };
   rc = body();
+  if (arriving) {   // the caller's stream ends up behind every piece, whatever the column structure above consumed
+    const int rc2 = need_columns(st, INT64_MAX);
+    if (rc == SMN_OK) rc = rc2;
+    if (rc != SMN_OK) (void)hipStreamSynchronize(ctx->stream_scatter);
+  }
   // The caller's stream continues after the bulk stream whatever happened above: an error exit must not leave F1 work
   // running behind a workspace the caller is about to free or reuse.
   if (bulk_busy) {

@@ -588,16 +588,15 @@ __global__ void __launch_bounds__(256, SMN_CNN32_OCC) conv_pair44_kernel(PairArg
 
 // Launch one form of the pair kernel.  Tiled pair order once there are >= 64 tiles per XCD: the grid is then exactly the
 // resident set (occupancy API; a multiple of 64 workgroups, so a tile is a whole number of 32-pair rows).
-// cnn_tiled: 0 never, 1 by size, 2 always (tests).
 template <typename T, typename K>
 int launch_pair_form(smn_ctx* ctx, K kern, PairArgs<T> a, int64_t blocks, size_t lds) {
   if (lds > 0)
     SMN_TRY(smn_allow_lds(ctx, reinterpret_cast<const void*>(kern), lds));
   int per_cu = 0;
-  if (ctx->cnn_tiled > 0 && hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, lds) == hipSuccess &&
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, lds) == hipSuccess &&
       per_cu > 0) {
     const int64_t g = (int64_t)ctx->num_cu * per_cu / 64 * 64;
-    if (g >= 64 && (ctx->cnn_tiled == 2 || a.npairs >= 64 * 8 * (g / 8) * 4)) {
+    if (g >= 64 && a.npairs >= 64 * 8 * (g / 8) * 4) {
       blocks = g;
       a.tile_bn = (int)(g / 64);
     }
@@ -610,12 +609,12 @@ int launch_pair_form(smn_ctx* ctx, K kern, PairArgs<T> a, int64_t blocks, size_t
 template <typename T, int ACT>
 int launch_pairs(smn_ctx* ctx, const PairArgs<T>& a, int64_t blocks, size_t lds, int64_t hw) {
   // register-only stencil, no LDS: fp64 by default (+2 ... +11 % with growing N; the fp32 LDS-map kernel is VALU-bound at
-  // 72 % busy and 5 % FASTER than its register form: profiles/r01f_cnn_fast32_ab.txt); cnn_fast32 = 2 forces it for both
-  if (a.prog.H == 32 && a.prog.W == 32 && (ctx->cnn_fast32 == 2 || (ctx->cnn_fast32 == 1 && sizeof(T) == 8))) {
+  // 72 % busy and 5 % FASTER than its register form: profiles/r01f_cnn_fast32_ab.txt)
+  if (a.prog.H == 32 && a.prog.W == 32 && sizeof(T) == 8) {
     // a 4x4 patch per lane where the patch rows are whole vectors (1 or 3 channels: MNIST- / CIFAR-shaped inputs)
     // (cnn_t made the same choice: the tables and a.x1 / a.x2 are in patch order then)
-    if (a.prog.C == 3 && ctx->cnn_patch44) return launch_pair_form<T>(ctx, conv_pair44_kernel<T, ACT, 3>, a, blocks, 0);
-    if (a.prog.C == 1 && ctx->cnn_patch44) return launch_pair_form<T>(ctx, conv_pair44_kernel<T, ACT, 1>, a, blocks, 0);
+    if (a.prog.C == 3) return launch_pair_form<T>(ctx, conv_pair44_kernel<T, ACT, 3>, a, blocks, 0);
+    if (a.prog.C == 1) return launch_pair_form<T>(ctx, conv_pair44_kernel<T, ACT, 1>, a, blocks, 0);
     return launch_pair_form<T>(ctx, conv_pair32_kernel<T, ACT>, a, blocks, 0);
   }
 #define PAIR_CASE(NP)                                                                                         \
@@ -644,8 +643,7 @@ int cnn_t(smn_ctx* ctx, int act, int layers, double w, double b, double lw, cons
   if (lds_q > 160 * 1024 || lds_p > 160 * 1024)
     return smn_fail(ctx, SMN_ENOTSUP, "smn_kernel_cnn: image %lldx%lld too large for the on-chip pair map", (long long)H, (long long)W);
   // tables: R1 [n1][L][HW], diag1 [n1] (+ R2, diag2); patch order + patch-order copies of the inputs for conv_pair44_kernel
-  const bool patch44 = H == 32 && W == 32 && (C == 1 || C == 3) && ctx->cnn_patch44 &&
-                       (ctx->cnn_fast32 == 2 || (ctx->cnn_fast32 == 1 && sizeof(T) == 8));
+  const bool patch44 = H == 32 && W == 32 && (C == 1 || C == 3) && sizeof(T) == 8;
   const size_t qn1 = (size_t)n1 * (size_t)(layers > 0 ? layers : 1) * HW, qn2 = sym ? 0 : (size_t)n2 * (size_t)(layers > 0 ? layers : 1) * HW;
   const size_t xn1 = patch44 ? (size_t)n1 * HW * C : 0, xn2 = (patch44 && !sym) ? (size_t)n2 * HW * C : 0;
   void* tv = nullptr;

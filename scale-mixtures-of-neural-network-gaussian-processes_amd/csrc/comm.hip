@@ -205,112 +205,72 @@ extern "C" int smn_unpack_lower_blocks(smn_ctx* ctx, int dtype, const void* stag
   return SMN_OK;
 }
 
-// ---------------------------------------------------------------- pipelined exchange: pieces of the chunks
-// Every rank's chunk (block_rows^2 (2P+1) elements, low block first) is cut into `parts` equal pieces.  Piece g of all
-// ranks is gathered as soon as the rank has built the tile rows it covers (sharding.py: part_tile_rows), into
-//   stage[g][rank][piece]          (piece = chunk / parts elements)
-// while the next piece is being built; a piece's scatter into K follows its gather on the same stream.  Pieces are
-// element ranges, not row ranges: the mapping below undoes the packing element by element (in 16-byte vectors: a
-// block's leading dimension and the piece length are multiples of 4 elements, so a vector never straddles a row or
-// a piece).
+// ---------------------------------------------------------------- column-first exchange: pieces of the cyclic layout
+// internal.hpp ColPieces: piece g of a rank's chunk is slots(g) strips of 128 x width(g) elements (its tile rows from tile
+// column c[g] down, columns [c[g], c[g+1]) * 128); all ranks' pieces g are gathered into stage[P * off[g] ...][rank][count(g)]
+// and scattered into the natural row order of K.  Strips are read and written in 16-byte vectors (a strip row and a piece
+// are multiples of 128 elements); entries right of the row's diagonal tile, rows >= n and the slots of tile rows past the
+// kernel are not written.
 namespace {
 
 template <typename T, int VEC>
-__global__ void unpack_part_kernel(const T* __restrict__ stage_g, int64_t piece, int64_t e0, int64_t h, int P, int64_t n,
-                                   T* __restrict__ k, int64_t ldk) {
-  const int64_t v = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * VEC;   // element inside [rank][piece]
-  if (v >= (int64_t)P * piece) return;
-  const int64_t r = v / piece;                 // owner rank
-  int64_t e = e0 + (v - r * piece);            // element of rank r's chunk
-  const int64_t low = h * (r + 1) * h;         // elements of its low block
-  int64_t b, ld;
-  if (e < low) {
-    b = r; ld = (r + 1) * h;
-  } else {
-    e -= low; b = 2 * (int64_t)P - 1 - r; ld = (2 * (int64_t)P - r) * h;
-  }
-  const int64_t row = b * h + e / ld, col = e % ld;
+__global__ void scatter_piece_kernel(const T* __restrict__ stage_g, int64_t count, int64_t width, int64_t c0, int P, int64_t T_rows,
+                                     int64_t n, T* __restrict__ k, int64_t ldk, double diag_add) {
+  const int64_t v = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * VEC;   // element inside [rank][count]
+  if (v >= (int64_t)P * count) return;
+  const int64_t r = v / count;                 // owner rank
+  const int64_t e = v - r * count;             // element of its piece
+  const int64_t srow = e / width, lc = e - srow * width;   // strip row (slot * 128 + row in tile), column inside the piece
+  const int64_t j = c0 / P + srow / kTile;     // tile-row group
+  const int64_t t = j * P + ((j & 1) ? P - 1 - r : r);
+  if (t >= T_rows) return;
+  const int64_t row = t * kTile + (srow % kTile), col = c0 * kTile + lc;
   if (row >= n) return;
-  int64_t cend = (row / kTile + 1) * kTile;
+  int64_t cend = (t + 1) * kTile;
   if (cend > n) cend = n;
   if (col >= cend) return;
   T* dst = k + row * ldk + col;
   const T* src = stage_g + v;
   if (VEC > 1 && col + VEC <= cend) {
     typedef T vec_t __attribute__((ext_vector_type(VEC)));
-    *reinterpret_cast<vec_t*>(dst) = *reinterpret_cast<const vec_t*>(src);
+    vec_t x = *reinterpret_cast<const vec_t*>(src);
+    if (diag_add != 0.0 && row >= col && row < col + VEC) x[row - col] = (T)((double)x[row - col] + diag_add);
+    *reinterpret_cast<vec_t*>(dst) = x;
   } else {
-    for (int i = 0; i < VEC && col + i < cend; ++i) dst[i] = src[i];
+    for (int i = 0; i < VEC && col + i < cend; ++i)
+      dst[i] = (diag_add != 0.0 && row == col + i) ? (T)((double)src[i] + diag_add) : src[i];
   }
-}
-
-int check_parts(smn_ctx* ctx, int dtype, int64_t n, int nranks, int64_t block_rows, int parts, int64_t* piece) {
-  if (dtype != SMN_F32 && dtype != SMN_F64) return smn_fail(ctx, SMN_EINVAL, "bad dtype");
-  if (n <= 0 || nranks <= 0 || block_rows <= 0 || block_rows % kTile || 2 * (int64_t)nranks * block_rows < n)
-    return smn_fail(ctx, SMN_EINVAL, "bad shard geometry (n=%lld ranks=%d block_rows=%lld)", (long long)n, nranks,
-                    (long long)block_rows);
-  const int64_t chunk = block_rows * block_rows * (2 * (int64_t)nranks + 1);
-  if (parts <= 0 || chunk % parts || (chunk / parts) % 4)
-    return smn_fail(ctx, SMN_EINVAL, "parts=%d must divide the chunk (%lld elements) into multiples of 4", parts, (long long)chunk);
-  *piece = chunk / parts;
-  return SMN_OK;
 }
 
 }  // namespace
 
-int unpack_parts_on(smn_ctx* ctx, hipStream_t st, int dtype, const void* stage_d, int64_t n, int nranks, int64_t block_rows,
-                    int parts, int part_begin, int part_end, void* k_d, int64_t ldk) {
-  int64_t piece = 0;
-  SMN_TRY(check_parts(ctx, dtype, n, nranks, block_rows, parts, &piece));
-  if (part_begin < 0 || part_end > parts || part_begin > part_end || ldk < n)
-    return smn_fail(ctx, SMN_EINVAL, "unpack: bad part range [%d,%d) of %d or ldk", part_begin, part_end, parts);
+int scatter_piece_on(smn_ctx* ctx, hipStream_t st, int dtype, const void* stage_d, int64_t n, const ColPieces& cp, int g,
+                     void* k_d, int64_t ldk, double diag_add) {
+  if (g < 0 || g >= cp.np || ldk < n) return smn_fail(ctx, SMN_EINVAL, "scatter: piece %d of %d, ldk %lld", g, cp.np, (long long)ldk);
   const size_t es = dtype_size(dtype);
   const int vec = (int)(16 / es);
-  const bool aligned = (ldk % vec == 0) && (reinterpret_cast<uintptr_t>(k_d) % 16 == 0) &&
-                       (reinterpret_cast<uintptr_t>(stage_d) % 16 == 0);
-  for (int g = part_begin; g < part_end; ++g) {
-    const char* sg = static_cast<const char*>(stage_d) + es * (size_t)g * (size_t)nranks * (size_t)piece;
-    const int64_t total = (int64_t)nranks * piece;
-#define UNPACKP(T, V)                                                                                          \
-  hipLaunchKernelGGL((unpack_part_kernel<T, V>), dim3((unsigned)((total / V + 255) / 256)), dim3(256), 0, st, \
-                     reinterpret_cast<const T*>(sg), piece, (int64_t)g * piece, block_rows, nranks, n,        \
-                     static_cast<T*>(k_d), ldk)
-    if (dtype == SMN_F64) {
-      if (aligned) UNPACKP(double, 2); else UNPACKP(double, 1);
-    } else {
-      if (aligned) UNPACKP(float, 4); else UNPACKP(float, 1);
-    }
-#undef UNPACKP
+  const char* sg = static_cast<const char*>(stage_d) + es * (size_t)cp.P * (size_t)cp.off[g];
+  const bool aligned = (ldk % vec == 0) && (reinterpret_cast<uintptr_t>(k_d) % 16 == 0) && (reinterpret_cast<uintptr_t>(sg) % 16 == 0);
+  const int64_t total = (int64_t)cp.P * cp.count(g);
+  const int64_t tile_rows = cp.T;
+#define SCATTERP(TY, V)                                                                                          \
+  hipLaunchKernelGGL((scatter_piece_kernel<TY, V>), dim3((unsigned)((total / V + 255) / 256)), dim3(256), 0, st, \
+                     reinterpret_cast<const TY*>(sg), cp.count(g), cp.width(g), cp.c[g], cp.P, tile_rows, n,    \
+                     static_cast<TY*>(k_d), ldk, diag_add)
+  if (dtype == SMN_F64) {
+    if (aligned) SCATTERP(double, 2); else SCATTERP(double, 1);
+  } else {
+    if (aligned) SCATTERP(float, 4); else SCATTERP(float, 1);
   }
+#undef SCATTERP
   SMN_CHECK_LAUNCH(ctx);
   return SMN_OK;
 }
 
-int allgather_part_on(smn_ctx* ctx, hipStream_t st, int dtype, const void* mine_d, void* stage_d, int64_t chunk_elems,
-                      int parts, int part) {
-  if (parts <= 0 || part < 0 || part >= parts || chunk_elems % parts)
-    return smn_fail(ctx, SMN_EINVAL, "allgather_part: part %d of %d over %lld elements", part, parts, (long long)chunk_elems);
-  const int64_t piece = chunk_elems / parts;
-  const int P = ctx->comm ? ctx->nranks : 1;
+int allgather_piece_on(smn_ctx* ctx, hipStream_t st, int dtype, const void* mine_d, void* stage_d, const ColPieces& cp, int g) {
+  if (g < 0 || g >= cp.np) return smn_fail(ctx, SMN_EINVAL, "all-gather: piece %d of %d", g, cp.np);
   const size_t es = dtype_size(dtype);
-  const char* send = static_cast<const char*>(mine_d) + es * (size_t)part * (size_t)piece;
-  char* recv = static_cast<char*>(stage_d) + es * (size_t)part * (size_t)P * (size_t)piece;
-  return allgather_on(ctx, st, dtype, send, recv, piece);
-}
-
-extern "C" int smn_unpack_lower_parts(smn_ctx* ctx, int dtype, const void* stage_d, int64_t n, int nranks,
-                                      int64_t block_rows, int parts, int part_begin, int part_end, void* k_d, int64_t ldk) {
-  if (!ctx || !stage_d || !k_d) return SMN_EINVAL;
-  SMN_ENTER(ctx);
-  ProfScope ps(ctx, PROF_MISC, ctx->stream);
-  return unpack_parts_on(ctx, ctx->stream, dtype, stage_d, n, nranks, block_rows, parts, part_begin, part_end, k_d, ldk);
-}
-
-extern "C" int smn_allgather_part(smn_ctx* ctx, int dtype, const void* mine_d, void* stage_d, int64_t chunk_elems,
-                                  int parts, int part) {
-  if (!ctx || !mine_d || !stage_d) return SMN_EINVAL;
-  SMN_ENTER(ctx);
-  if (dtype != SMN_F32 && dtype != SMN_F64) return smn_fail(ctx, SMN_EINVAL, "bad dtype");
-  ProfScope ps(ctx, PROF_COMM, ctx->stream);
-  return allgather_part_on(ctx, ctx->stream, dtype, mine_d, stage_d, chunk_elems, parts, part);
+  const char* send = static_cast<const char*>(mine_d) + es * (size_t)cp.off[g];
+  char* recv = static_cast<char*>(stage_d) + es * (size_t)cp.P * (size_t)cp.off[g];
+  return allgather_on(ctx, st, dtype, send, recv, cp.count(g));
 }

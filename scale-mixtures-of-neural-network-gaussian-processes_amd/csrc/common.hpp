@@ -20,31 +20,20 @@ struct smn_ctx {
   hipStream_t stream_bulk = nullptr;  // CU-masked stream of the far updates F1: may not use the first chain_cus CUs
   int chain_cus = 32;                 // CUs kept free for the panel chain (env SMN_CHAIN_CUS; 0 = no look-ahead)
   int64_t chain_min_n = 8192;         // look-ahead only from this matrix size on (env SMN_CHAIN_MIN_N)
-  int64_t f0_first_tiles = 2000;      // F1 launches of at most this many tiles start behind F0, not beside it (env SMN_F0_FIRST_TILES; 0: never)
-  hipStream_t stream_scatter = nullptr;   // the scatter of a gathered piece into the workspace: beside the NEXT piece's all-gather (link-bound), not in front of it
-  hipEvent_t ev_g = nullptr;              // comm stream -> scatter stream (re-recorded per piece)
-  hipStream_t stream_comm = nullptr;  // the pipelined exchange: all-gather + scatter of one piece while the next one is being built (high priority)
-  hipStream_t stream_build = nullptr; // sharded builds beside a live exchange: may not use the first comm_cus CUs, which RCCL's kernels then always find free
-  int comm_cus = 16;                  // env SMN_COMM_CUS (0: sharded builds stay on the main stream); 8-32 keep the XCDs balanced (profiles/r02_xcc_placement_probe.txt)
-  bool comm_cus_force = false;        // env SMN_COMM_CUS_FORCE=1: mask the sharded build without a multi-rank communicator too (one-GPU rehearsal)
-  hipEvent_t ev_b0 = nullptr, ev_b1 = nullptr;   // main -> build stream, build stream -> main
-  // Pieces of a pipelined sharded build (between smn_shard_begin and smn_lml_from_shards) rotate over the masked build
-  // streams and are NOT joined into the main stream one by one: the tail of one piece's launch (a few hundred tiles are about
-  // one tile per CU) runs under the head of the next.  ev_bd[i] = the last build launched on build stream i.
-  static constexpr int kBuildStreams = 4;   // stream_build + the three below (fewer if their creation failed)
-  hipStream_t stream_bx[kBuildStreams - 1] = {nullptr, nullptr, nullptr};
-  int n_build_streams = 1;
-  hipEvent_t ev_bd[kBuildStreams] = {nullptr, nullptr, nullptr, nullptr};
-  int64_t shard_half_tiles_max = 600;   // sharded f32 build launches of at most this many 128x128 tiles use 64-row half tiles (env SMN_SHARD_HALF_TILES; 0: never)
-  unsigned build_seq = 0;
-  unsigned builds_pending = 0;   // bit i: ev_bd[i] has been recorded since the last join
+  hipStream_t stream_comm = nullptr;     // column-first exchange: the all-gathers of the pieces, one after the other (high priority)
+  hipStream_t stream_scatter = nullptr;  // the scatter of a gathered piece into the workspace: beside the NEXT piece's all-gather (link-bound), not in front of it
   hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
-  hipEvent_t ev_c0 = nullptr, ev_c1 = nullptr;   // main -> comm (piece built), comm -> main (all pieces scattered)
-  // factorisation workspace prepared by smn_shard_begin for the pipelined exchange (slot 2)
-  void* shard_a = nullptr; int64_t shard_lda = 0, shard_n = 0; int shard_dtype = -1;
-  // which x the padded operand in slot 0 was made from (smn_kernel_mlp_shard_rows with reuse_operand); any other request
-  // for slot 0 clears it
-  const void* op_x = nullptr; int64_t op_n = 0, op_d = 0, op_ldx = 0; int op_dtype = -1;
+  hipEvent_t ev_c0 = nullptr, ev_c1 = nullptr;   // main -> comm (the rank's share is built, the workspace is up); scatter -> main (every piece issued so far has landed)
+  // Column-first exchange (smn_shard_begin ... smn_lml_from_shards): the factorisation workspace (slot 2) the pieces are
+  // scattered into, the absolute jitter the scatter adds to the diagonal entries it writes, and one Arrival per piece issued:
+  // columns [col_begin, col_end) of the workspace are complete once `ev` has fired.  The factorisation waits piece by piece
+  // (cholesky.hip need_columns): the panel chain of a super-panel for its own columns only, the far update for the rest.
+  void* shard_a = nullptr; int64_t shard_lda = 0, shard_n = 0; int shard_dtype = -1; double shard_eps = 0.0;
+  struct Arrival { int64_t col_begin, col_end; hipEvent_t ev; };
+  std::vector<Arrival> arrivals;          // in issue order; cleared by smn_shard_begin and by the factorisation that consumed them
+  bool consume_arrivals = false;          // set by smn_lml_from_shards around its factorisation
+  std::vector<hipEvent_t> ev_pool;        // events of the pieces (gathered / arrived), reused from pipeline to pipeline
+  size_t ev_pool_used = 0;
   std::string err;
   // cached workspace arenas (grown on demand, freed with the context)
   static constexpr int kSlots = 10;
@@ -68,8 +57,8 @@ struct smn_ctx {
   double prof_flops[12] = {};         // MFMA flops EXECUTED per category since smn_profile_enable (whole tiles; host-side count)
   int num_cu = 256;                  // hipDeviceProp_t::multiProcessorCount
   int64_t super_panel = 1024;        // columns per super-panel of the two-level Cholesky (env SMN_SUPER)
-  int64_t super_panel_wide = 2048;   // ... while at least super_wide_rows rows are left (env SMN_SUPER_WIDE, SMN_SUPER_WIDE_ROWS)
-  int64_t super_wide_rows = 18432;   // (measured: wide pays from ~18k rows left on, profiles/r02_wide_super_panel_sweep.txt; 0 rows = always wide)
+  int64_t super_wide_rows = 18432;   // super-panels are kSuperWide columns while at least this many rows are left (env SMN_SUPER_WIDE_ROWS;
+                                     // measured: wide pays from ~18k rows left on, profiles/r02_wide_super_panel_sweep.txt; 0 rows = always wide)
   // structural-zero hint for the factorisation in flight: appended rows [id0, id1) hold an identity block
   // (row id0 + i is zero left of column i), set by cholesky_padded, -1 = none
   int64_t chol_id0 = -1, chol_id1 = -1;
@@ -77,16 +66,11 @@ struct smn_ctx {
   std::unordered_map<const void*, size_t> max_lds;   // largest dynamic-LDS size already allowed per kernel (smn_allow_lds)
   bool lds_attrs_done[2] = {false, false};   // hipFuncSetAttribute(MaxDynamicSharedMemorySize) issued for f32 / f64 kernels
   bool panel_leaf = true;            // panelr_kernel (register-resident 16x16 leaf) in the factorisation; env SMN_PANEL_LEAF=0: panel_kernel
-  int cnn_fast32 = 1;                // conv-NNGP: register-only 3x3 stencil for 32x32 images (env SMN_CNN_FAST32: 0 never, 1 fp64 only, 2 both)
-  bool cnn_patch44 = true;           // conv-NNGP, 32x32 images with 1 or 3 channels: 4x4 pixel patch per lane (env SMN_CNN_PATCH44=0: one row pair per half-wave)
-  int cnn_tiled = 1;                 // conv-NNGP pair kernel: XCD-tiled pair order for large problems (env SMN_CNN_TILED: 0 never, 2 always)
-  bool rec_sym = true;               // stand-alone recursion: lower-tile + mirror kernel when symmetric (env SMN_REC_SYM=0)
-  bool persistent_trail = true;      // persistent trailing-update kernel (env SMN_PERSISTENT=0 disables)
   bool xcd_map = true;               // XCD-aware patch tile order of launches of 512 tiles and more (env SMN_XCD_MAP=0: linear order)
 };
 
 enum { PROF_PREP = 0, PROF_BUILD = 1, PROF_RECURSION = 2, PROF_PANEL = 3, PROF_STRIP = 4, PROF_TRAIL = 5,
-       PROF_MISC = 6, PROF_COMM = 7, PROF_EXPOSED = 8, PROF_BUILD_WAIT = 9, PROF_NCAT = 10 };
+       PROF_MISC = 6, PROF_COMM = 7, PROF_EXPOSED = 8, PROF_STALL = 9, PROF_NCAT = 10 };
 
 // Brackets the launches issued during its lifetime with an event pair when profiling is on.
 struct ProfScope {

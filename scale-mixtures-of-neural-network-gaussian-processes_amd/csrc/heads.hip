@@ -14,6 +14,7 @@
 //   the quadratic form of StudentTLikelihood.logpdf      spax/likelihoods.py:60-61
 // The closed-form log-pdf arithmetic on the resulting scalars is done on the host (lgamma etc.).
 #include <cmath>
+#include <vector>
 
 #include "internal.hpp"
 
@@ -231,141 +232,200 @@ extern "C" int smn_lml_from_blocks(smn_ctx* ctx, int dtype, const void* stage_d,
   return SMN_OK;
 }
 
-// ---- the pipelined multi-GPU route ("chunk by row-panels and overlap with compute") ----
-//   smn_shard_begin            factorisation workspace up (padding rows cleared), before the first piece arrives
-//   smn_kernel_mlp_shard_rows  (kernel_build.hip) this rank builds the tile rows that complete the next piece
-//   smn_shard_exchange_part    that piece: all-gather + scatter into the workspace, on the communication stream,
-//                              ordered after the build launches issued so far -- the next piece's build runs beside it
-//   smn_lml_from_shards        the context's stream waits for the last piece, then the factorisation and the head
-// Builds of a pipelined exchange that have not been joined yet (kernel_build.hip launch_build_t): `st` waits for them.
-static int wait_pending_builds(smn_ctx* ctx, hipStream_t st, bool clear) {
-  if (!ctx->builds_pending) return SMN_OK;
-  auto waits = [&]() -> int {
-    for (int i = 0; i < smn_ctx::kBuildStreams; ++i)
-      if (ctx->builds_pending & (1u << i)) SMN_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_bd[i], 0));
-    return SMN_OK;
-  };
-  if (st == ctx->stream) {
-    // on the main stream this wait IS the wall time of the pieces' builds (the stream has been idle since smn_shard_begin)
-    ProfScope ps(ctx, PROF_BUILD_WAIT, st);
-    SMN_TRY(waits());
-  } else {
-    SMN_TRY(waits());
+// ---- the column-first multi-GPU route ("chunk ... and overlap with compute") ----
+//   smn_shard_begin            factorisation workspace up (padding rows cleared) before the first piece arrives; states the
+//                              absolute jitter, which the scatter adds to the diagonal entries as it writes them
+//   smn_kernel_mlp_shard_cols  (kernel_build.hip) the rank's whole share of the build: ONE launch on every CU
+//   smn_shard_exchange_cols    piece g (a column range of the lower triangle, every rank's share of it): all-gather on the
+//                              communication stream, scatter into the workspace on the scatter stream, and an Arrival
+//                              {columns, event} for the factorisation.  Returns at once.
+//   smn_lml_from_shards        factorisation + head.  The main stream waits PIECE BY PIECE (cholesky.hip need_columns): the
+//                              panel chain of a super-panel for that super-panel's columns, F0 for the next one's, the bulk far
+//                              update for all -- so only the first piece's gather + scatter is exposed, the rest of the exchange
+//                              rides under the first panel chain.
+namespace {
+
+__global__ void delay_kernel(long long ticks) {   // test hook: holds a stream for a bounded time (100 MHz wall clock)
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+
+int pool_event(smn_ctx* ctx, hipEvent_t* ev) {
+  if (ctx->ev_pool_used == ctx->ev_pool.size()) {
+    hipEvent_t e;
+    SMN_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    ctx->ev_pool.push_back(e);
   }
-  if (clear) ctx->builds_pending = 0;
+  *ev = ctx->ev_pool[ctx->ev_pool_used++];
   return SMN_OK;
 }
 
-extern "C" int smn_shard_begin(smn_ctx* ctx, int dtype, int64_t n) {
+int check_exchange(smn_ctx* ctx, const char* who, int dtype, int64_t n, int nranks, bool to_workspace) {
+  if (dtype != SMN_F32 && dtype != SMN_F64) return smn_fail(ctx, SMN_EINVAL, "bad dtype");
+  if (to_workspace) {
+    if (!ctx->shard_a || ctx->shard_n != n || ctx->shard_dtype != dtype)
+      return smn_fail(ctx, SMN_EINVAL, "%s: smn_shard_begin(dtype, n, eps) first", who);
+    if (ctx->ws[2] != ctx->shard_a) return smn_fail(ctx, SMN_EINVAL, "%s: the workspace moved since smn_shard_begin", who);
+  }
+  const int P = ctx->comm ? ctx->nranks : 1;
+  if (nranks != P)   // a world > 1 call on a context without a communicator would quietly gather nothing
+    return smn_fail(ctx, SMN_ECOMM, "%s: %d ranks asked for, the context's communicator has %d", who, nranks, P);
+  return SMN_OK;
+}
+
+// scatter of piece g on the scatter stream behind `after` (an event on whichever stream filled the staging buffer); into the
+// factorisation workspace (k_d == nullptr: jitter on the diagonal, an Arrival for the factorisation) or a matrix of the caller's
+int scatter_piece(smn_ctx* ctx, int dtype, const void* stage_d, int64_t n, const ColPieces& cp, int g, hipEvent_t after,
+                  void* k_d, int64_t ldk) {
+  hipStream_t ss = ctx->stream_scatter;
+  SMN_HIP(ctx, hipStreamWaitEvent(ss, after, 0));
+  {
+    ProfScope ps(ctx, PROF_MISC, ss);
+    if (k_d) SMN_TRY(scatter_piece_on(ctx, ss, dtype, stage_d, n, cp, g, k_d, ldk, 0.0));
+    else SMN_TRY(scatter_piece_on(ctx, ss, dtype, stage_d, n, cp, g, ctx->shard_a, ctx->shard_lda, ctx->shard_eps));
+  }
+  if (!k_d) {
+    hipEvent_t arrived;
+    SMN_TRY(pool_event(ctx, &arrived));
+    SMN_HIP(ctx, hipEventRecord(arrived, ss));
+    int64_t hi = cp.c[g + 1] * kTile;
+    if (hi > n) hi = n;
+    ctx->arrivals.push_back({cp.c[g] * kTile, hi, arrived});
+  }
+  SMN_HIP(ctx, hipEventRecord(ctx->ev_c1, ss));   // "everything issued so far has landed" (smn_shard_wait)
+  return SMN_OK;
+}
+
+int exchange_piece(smn_ctx* ctx, const char* who, int dtype, const void* mine_d, void* stage_d, int64_t n, int nranks, int npieces,
+                   const int64_t* piece_cols, int piece, void* k_d, int64_t ldk) {
+  SMN_TRY(check_exchange(ctx, who, dtype, n, nranks, k_d == nullptr));
+  ColPieces cp;
+  SMN_TRY(col_pieces_make(ctx, n, nranks, npieces, piece_cols, &cp));
+  if (piece < 0 || piece >= npieces) return smn_fail(ctx, SMN_EINVAL, "%s: piece %d of %d", who, piece, npieces);
+  hipStream_t sc = ctx->stream_comm;
+  SMN_HIP(ctx, hipEventRecord(ctx->ev_c0, ctx->stream));      // the rank's share is built and the workspace is up
+  SMN_HIP(ctx, hipStreamWaitEvent(sc, ctx->ev_c0, 0));
+  {
+    ProfScope ps(ctx, PROF_COMM, sc);
+    SMN_TRY(allgather_piece_on(ctx, sc, dtype, mine_d, stage_d, cp, piece));
+  }
+  // The scatter has its own stream: the NEXT piece's all-gather (link-bound) starts at once, not behind this scatter (HBM-bound).
+  hipEvent_t gathered;
+  SMN_TRY(pool_event(ctx, &gathered));
+  SMN_HIP(ctx, hipEventRecord(gathered, sc));
+  return scatter_piece(ctx, dtype, stage_d, n, cp, piece, gathered, k_d, ldk);
+}
+
+}  // namespace
+
+extern "C" int smn_shard_begin(smn_ctx* ctx, int dtype, int64_t n, double eps_abs) {
   if (!ctx) return SMN_EINVAL;
   SMN_ENTER(ctx);
   if (dtype != SMN_F32 && dtype != SMN_F64) return smn_fail(ctx, SMN_EINVAL, "bad dtype");
   if (n <= 0) return smn_fail(ctx, SMN_EINVAL, "smn_shard_begin: empty");
-  SMN_TRY(wait_pending_builds(ctx, ctx->stream, true));   // (an abandoned pipeline's builds)
+  if (!ctx->arrivals.empty()) {   // an abandoned pipeline: its pieces may still be landing in the workspace about to be cleared
+    SMN_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_c1, 0));
+    ctx->arrivals.clear();
+  }
+  ctx->ev_pool_used = 0;
   Aug g;
   SMN_TRY(aug_alloc(ctx, dtype, n, 0, 1, &g));
   SMN_HIP(ctx, hipMemsetAsync(g.at(n, 0), 0, g.es * (size_t)(g.n_total - n) * (size_t)g.lda, ctx->stream));
   SMN_TRY(fill_identity_pad(ctx, dtype, g.a, g.lda, g.n_pad, n));
-  ctx->shard_a = g.a; ctx->shard_lda = g.lda; ctx->shard_n = n; ctx->shard_dtype = dtype;
+  ctx->shard_a = g.a; ctx->shard_lda = g.lda; ctx->shard_n = n; ctx->shard_dtype = dtype; ctx->shard_eps = eps_abs;
   return SMN_OK;
 }
 
-extern "C" int smn_shard_exchange_part(smn_ctx* ctx, int dtype, const void* mine_d, void* stage_d, int64_t n, int nranks,
-                                       int64_t block_rows, int parts, int part) {
+extern "C" int smn_shard_exchange_cols(smn_ctx* ctx, int dtype, const void* mine_d, void* stage_d, int64_t n, int nranks,
+                                       int npieces, const int64_t* piece_cols, int piece) {
   if (!ctx || !mine_d || !stage_d) return SMN_EINVAL;
   SMN_ENTER(ctx);
-  if (!ctx->shard_a || ctx->shard_n != n || ctx->shard_dtype != dtype)
-    return smn_fail(ctx, SMN_EINVAL, "smn_shard_exchange_part: smn_shard_begin(dtype, n) first");
-  if (ctx->ws[2] != ctx->shard_a)
-    return smn_fail(ctx, SMN_EINVAL, "smn_shard_exchange_part: the workspace moved since smn_shard_begin");
-  const int P = ctx->comm ? ctx->nranks : 1;
-  if (nranks != P)   // a world > 1 call on a context without a communicator would quietly gather nothing
-    return smn_fail(ctx, SMN_ECOMM, "smn_shard_exchange_part: %d ranks asked for, the context's communicator has %d", nranks, P);
-  const int64_t chunk = block_rows * block_rows * (2 * (int64_t)nranks + 1);
-  hipStream_t sc = ctx->stream_comm;
-  SMN_HIP(ctx, hipEventRecord(ctx->ev_c0, ctx->stream));      // the piece is built (and, for part 0, the workspace is up)
-  SMN_HIP(ctx, hipStreamWaitEvent(sc, ctx->ev_c0, 0));
-  SMN_TRY(wait_pending_builds(ctx, sc, false));                // ... on a build stream, if the pieces are not joined one by one
-  {
-    ProfScope ps(ctx, PROF_COMM, sc);
-    SMN_TRY(allgather_part_on(ctx, sc, dtype, mine_d, stage_d, chunk, parts, part));
-  }
-  // The scatter has its own stream: the NEXT piece's all-gather (link-bound) starts as soon as its build is done, not behind
-  // this scatter (HBM-bound, and beside a live build confined to the CUs the build leaves free).
-  hipStream_t ss = ctx->stream_scatter;
-  SMN_HIP(ctx, hipEventRecord(ctx->ev_g, sc));
-  SMN_HIP(ctx, hipStreamWaitEvent(ss, ctx->ev_g, 0));
-  {
-    ProfScope ps(ctx, PROF_MISC, ss);
-    SMN_TRY(unpack_parts_on(ctx, ss, dtype, stage_d, n, nranks, block_rows, parts, part, part + 1, ctx->shard_a, ctx->shard_lda));
-  }
-  SMN_HIP(ctx, hipEventRecord(ctx->ev_c1, ss));
-  return SMN_OK;
+  return exchange_piece(ctx, "smn_shard_exchange_cols", dtype, mine_d, stage_d, n, nranks, npieces, piece_cols, piece, nullptr, 0);
 }
 
 // The same exchange of one piece, scattered into a matrix of the caller's (the NTK of a joint NNGP + NTK shard: BASELINE
-// config 5) instead of the factorisation workspace.  Same stream, same ordering: behind everything issued so far on the main
-// stream; smn_lml_from_shards (or smn_shard_wait) makes the main stream wait for every piece issued before it.
-extern "C" int smn_shard_exchange_part_to(smn_ctx* ctx, int dtype, const void* mine_d, void* stage_d, int64_t n, int nranks,
-                                          int64_t block_rows, int parts, int part, void* k_d, int64_t ldk) {
+// config 5) instead of the factorisation workspace: no jitter, no Arrival; smn_shard_wait (or smn_lml_from_shards) makes the
+// main stream wait for every piece issued before it.
+extern "C" int smn_shard_exchange_cols_to(smn_ctx* ctx, int dtype, const void* mine_d, void* stage_d, int64_t n, int nranks,
+                                          int npieces, const int64_t* piece_cols, int piece, void* k_d, int64_t ldk) {
   if (!ctx || !mine_d || !stage_d || !k_d) return SMN_EINVAL;
   SMN_ENTER(ctx);
-  if (dtype != SMN_F32 && dtype != SMN_F64) return smn_fail(ctx, SMN_EINVAL, "bad dtype");
-  if (n <= 0 || ldk < n) return smn_fail(ctx, SMN_EINVAL, "smn_shard_exchange_part_to: bad sizes");
-  const int P = ctx->comm ? ctx->nranks : 1;
-  if (nranks != P)
-    return smn_fail(ctx, SMN_ECOMM, "smn_shard_exchange_part_to: %d ranks asked for, the context's communicator has %d", nranks, P);
-  const int64_t chunk = block_rows * block_rows * (2 * (int64_t)nranks + 1);
-  hipStream_t sc = ctx->stream_comm;
-  SMN_HIP(ctx, hipEventRecord(ctx->ev_c0, ctx->stream));
-  SMN_HIP(ctx, hipStreamWaitEvent(sc, ctx->ev_c0, 0));
-  SMN_TRY(wait_pending_builds(ctx, sc, false));
-  {
-    ProfScope ps(ctx, PROF_COMM, sc);
-    SMN_TRY(allgather_part_on(ctx, sc, dtype, mine_d, stage_d, chunk, parts, part));
-  }
-  hipStream_t ss = ctx->stream_scatter;
-  SMN_HIP(ctx, hipEventRecord(ctx->ev_g, sc));
-  SMN_HIP(ctx, hipStreamWaitEvent(ss, ctx->ev_g, 0));
-  {
-    ProfScope ps(ctx, PROF_MISC, ss);
-    SMN_TRY(unpack_parts_on(ctx, ss, dtype, stage_d, n, nranks, block_rows, parts, part, part + 1, k_d, ldk));
-  }
-  SMN_HIP(ctx, hipEventRecord(ctx->ev_c1, ss));
-  return SMN_OK;
+  if (n <= 0 || ldk < n) return smn_fail(ctx, SMN_EINVAL, "smn_shard_exchange_cols_to: bad sizes");
+  return exchange_piece(ctx, "smn_shard_exchange_cols_to", dtype, mine_d, stage_d, n, nranks, npieces, piece_cols, piece, k_d, ldk);
 }
 
-// The main stream waits for every piece issued so far (for callers of smn_shard_exchange_part_to that do not finish with
+// The scatter half alone, for a staging buffer the caller filled on the main stream (tests that play P ranks on one GPU;
+// a caller with its own transport): piece g of stage_d [P * elements per rank] into the workspace (k_d == NULL) or k_d.
+extern "C" int smn_shard_scatter_cols(smn_ctx* ctx, int dtype, const void* stage_d, int64_t n, int nranks, int npieces,
+                                      const int64_t* piece_cols, int piece, void* k_d, int64_t ldk) {
+  if (!ctx || !stage_d) return SMN_EINVAL;
+  SMN_ENTER(ctx);
+  if (dtype != SMN_F32 && dtype != SMN_F64) return smn_fail(ctx, SMN_EINVAL, "bad dtype");
+  if (!k_d) {
+    if (!ctx->shard_a || ctx->shard_n != n || ctx->shard_dtype != dtype)
+      return smn_fail(ctx, SMN_EINVAL, "smn_shard_scatter_cols: smn_shard_begin(dtype, n, eps) first");
+    if (ctx->ws[2] != ctx->shard_a) return smn_fail(ctx, SMN_EINVAL, "smn_shard_scatter_cols: the workspace moved since smn_shard_begin");
+  } else if (ldk < n) {
+    return smn_fail(ctx, SMN_EINVAL, "smn_shard_scatter_cols: ldk < n");
+  }
+  ColPieces cp;
+  SMN_TRY(col_pieces_make(ctx, n, nranks, npieces, piece_cols, &cp));
+  if (piece < 0 || piece >= npieces) return smn_fail(ctx, SMN_EINVAL, "smn_shard_scatter_cols: piece %d of %d", piece, npieces);
+  hipEvent_t filled;
+  SMN_TRY(pool_event(ctx, &filled));
+  SMN_HIP(ctx, hipEventRecord(filled, ctx->stream));
+  return scatter_piece(ctx, dtype, stage_d, n, cp, piece, filled, k_d, ldk);
+}
+
+// The main stream waits for every piece issued so far (for callers of smn_shard_exchange_cols_to that do not finish with
 // smn_lml_from_shards).
 extern "C" int smn_shard_wait(smn_ctx* ctx) {
   if (!ctx) return SMN_EINVAL;
   SMN_ENTER(ctx);
-  SMN_TRY(wait_pending_builds(ctx, ctx->stream, true));
-  ProfScope ps(ctx, PROF_EXPOSED, ctx->stream);
+  ProfScope ps(ctx, PROF_STALL, ctx->stream);
   SMN_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_c1, 0));
   return SMN_OK;
 }
 
-extern "C" int smn_lml_from_shards(smn_ctx* ctx, int dtype, int64_t n, const void* y_d, double eps_abs, double df,
-                                   double scale, double* logpdf_h, double* quad_h, double* logdet_h, int* info_h) {
+// Test hook: hold one of the context's streams (0 main, 1 communication, 2 scatter) for `usec` microseconds (at most 1 s), so a
+// test can make pieces arrive late or out of order.
+extern "C" int smn_debug_delay(smn_ctx* ctx, int stream_id, int64_t usec) {
+  if (!ctx || stream_id < 0 || stream_id > 2 || usec < 0 || usec > 1000000) return SMN_EINVAL;
+  SMN_ENTER(ctx);
+  hipStream_t st = stream_id == 0 ? ctx->stream : (stream_id == 1 ? ctx->stream_comm : ctx->stream_scatter);
+  hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(64), 0, st, (long long)usec * 100);
+  SMN_CHECK_LAUNCH(ctx);
+  return SMN_OK;
+}
+
+extern "C" int smn_lml_from_shards(smn_ctx* ctx, int dtype, int64_t n, const void* y_d, double df, double scale,
+                                   double* logpdf_h, double* quad_h, double* logdet_h, int* info_h) {
   if (!ctx || !y_d) return SMN_EINVAL;
   SMN_ENTER(ctx);
   if (!ctx->shard_a || ctx->shard_n != n || ctx->shard_dtype != dtype)
-    return smn_fail(ctx, SMN_EINVAL, "smn_lml_from_shards: smn_shard_begin(dtype, n) first");
+    return smn_fail(ctx, SMN_EINVAL, "smn_lml_from_shards: smn_shard_begin(dtype, n, eps) first");
   if (df > 0.0 && !(scale > 0.0)) return smn_fail(ctx, SMN_EINVAL, "smn_lml_from_shards: scale must be > 0");
-  SMN_TRY(wait_pending_builds(ctx, ctx->stream, true));   // the pieces' builds first (they ran on the build streams) ...
-  {
-    // ... so that this measures what of the exchange is NOT hidden behind the build: the wait for the last piece
-    ProfScope ps(ctx, PROF_EXPOSED, ctx->stream);
-    SMN_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_c1, 0));
-  }
   Aug g;
   SMN_TRY(aug_alloc(ctx, dtype, n, 0, 1, &g));       // the same slot and size: no reallocation
   if (g.a != ctx->shard_a) return smn_fail(ctx, SMN_EINVAL, "smn_lml_from_shards: the workspace moved since smn_shard_begin");
-  ctx->shard_a = nullptr;
+  // every column of the kernel must have been issued as a piece (the factorisation waits for Arrivals, not for the streams)
+  {
+    std::vector<char> have((size_t)g.n_pad / kTile, 0);
+    for (const auto& a : ctx->arrivals)
+      for (int64_t c = a.col_begin / kTile; c < (a.col_end + kTile - 1) / kTile; ++c) have[(size_t)c] = 1;
+    for (int64_t c = 0; c < (n + kTile - 1) / kTile; ++c)
+      if (!have[(size_t)c]) return smn_fail(ctx, SMN_EINVAL, "smn_lml_from_shards: tile column %lld was never exchanged", (long long)c);
+  }
   double quad = 0.0, ld = 0.0;
   int info = 0;
-  SMN_TRY(aug_finish(ctx, dtype, g, y_d, 1, n, eps_abs, 0.0, nullptr, nullptr, 0, &quad, &ld, &info));
+  // jitter_abs = 0: the scatter added it already.  The factorisation consumes the Arrivals and leaves the main stream behind
+  // all of them.
+  ctx->consume_arrivals = true;
+  const int rc = aug_finish(ctx, dtype, g, y_d, 1, n, 0.0, 0.0, nullptr, nullptr, 0, &quad, &ld, &info);
+  ctx->consume_arrivals = false;
+  ctx->arrivals.clear();
+  ctx->shard_a = nullptr;
+  SMN_TRY(rc);
   if (logpdf_h) *logpdf_h = logpdf_from(quad, ld, n, df, scale, info);
   if (quad_h) *quad_h = quad;
   if (logdet_h) *logdet_h = ld;

@@ -3,6 +3,25 @@
 #include "common.hpp"
 
 constexpr int kTile = 128;   // GEMM block edge; every padded dimension is a multiple of it
+constexpr int kMaxColPieces = 16;   // pieces of a column-first exchange
+
+// Cyclic column-first shard of the symmetric kernel build over P ranks (host side: sharding.py, same formulas).
+//   tile rows (128 rows) are dealt in boustrophedon order with period 2P: group j = tile rows [jP, (j+1)P), rank r owns
+//   t_j(r) = jP + (j even ? r : P-1-r)  -- tile row t holds t+1 lower tiles, and every pair of groups gives every rank the same
+//   number of them, so the build is balanced and EVERY aligned group of P tile rows holds exactly one tile row per rank;
+//   piece g = tile columns [c[g], c[g+1]) (c[g] a multiple of P) of every tile row from c[g] down: slots = ceil((T - c[g]) / P)
+//   strips of 128 x (c[g+1]-c[g])*128 elements per rank -- the same count on every rank, so ONE equal-count all-gather moves a
+//   whole column range of the lower triangle (the tile rows that start inside it carry their above-diagonal tiles as padding).
+struct ColPieces {
+  int P = 1, np = 0;
+  int64_t T = 0;                       // tile rows of the kernel: ceil(n / 128)
+  int64_t c[kMaxColPieces + 1] = {};   // tile-column boundaries, c[0] = 0, c[np] = T
+  int64_t off[kMaxColPieces + 1] = {}; // element offset of piece g in a rank's chunk; off[np] = elements per rank
+  int64_t slots(int g) const { return (T - c[g] + P - 1) / P; }
+  int64_t width(int g) const { return (c[g + 1] - c[g]) * kTile; }
+  int64_t count(int g) const { return slots(g) * kTile * width(g); }
+};
+int col_pieces_make(smn_ctx* ctx, int64_t n, int nranks, int npieces, const int64_t* piece_cols, ColPieces* out);
 
 struct BuildSpec {
   int dtype, net, act, num_hiddens;
@@ -32,6 +51,8 @@ struct BuildCall {
   // paired lower-block shard (symmetric operands): two tile-aligned row blocks [rb,re), each written as
   // rows x columns [0,re) into its own packed output of leading dimension shard_ld
   int shard; int64_t shard_rb[2], shard_re[2]; void* shard_k[2]; void* shard_t[2]; int64_t shard_ld[2];
+  // shard == 2: cyclic column-first shard (ColPieces below); shard_k[0] / shard_t[0] = the rank's chunk
+  int cy_P, cy_rank, cy_np; int64_t cy_c[kMaxColPieces + 1]; int64_t cy_off[kMaxColPieces];
 };
 int run_build(smn_ctx* ctx, const BuildCall& c);
 
@@ -83,8 +104,8 @@ int transpose_matrix(smn_ctx* ctx, int dtype, void* dst, int64_t ldd, const void
 int flip_transpose_lower(smn_ctx* ctx, int dtype, void* dst, int64_t ldd, const void* src, int64_t lds, int64_t n);
 int transpose_flip(smn_ctx* ctx, int dtype, void* dst, int64_t ldd, const void* src, int64_t lds, int64_t rows,
                    int64_t cols, int flip_src_rows, int flip_dst_rows);
-// pipelined exchange (comm.hip): piece `part` of every rank's chunk, on stream `st`
-int allgather_part_on(smn_ctx* ctx, hipStream_t st, int dtype, const void* mine_d, void* stage_d, int64_t chunk_elems,
-                      int parts, int part);
-int unpack_parts_on(smn_ctx* ctx, hipStream_t st, int dtype, const void* stage_d, int64_t n, int nranks, int64_t block_rows,
-                    int parts, int part_begin, int part_end, void* k_d, int64_t ldk);
+// column-first exchange (comm.hip): the all-gather of piece g on stream `st`, and its scatter into k (lower triangle by
+// 128-column tiles; diag_add is added to the diagonal entries as they are written: the absolute jitter of SPR.loss)
+int allgather_piece_on(smn_ctx* ctx, hipStream_t st, int dtype, const void* mine_d, void* stage_d, const ColPieces& cp, int g);
+int scatter_piece_on(smn_ctx* ctx, hipStream_t st, int dtype, const void* stage_d, int64_t n, const ColPieces& cp, int g,
+                     void* k_d, int64_t ldk, double diag_add);

@@ -14,6 +14,8 @@
 
 namespace {
 
+constexpr int64_t kHalfTileBuildMax = 600;   // f32 build launches of at most this many 128x128 tiles use 64-row half tiles
+
 // ------------------------------------------------------------------ prep kernels
 template <typename T>
 __global__ void pad_rows_kernel(const T* __restrict__ src, int64_t n, int64_t lds, int64_t d,
@@ -104,6 +106,11 @@ struct BuildArgs {
   // paired lower-block shard (smn_kernel_mlp_shard): two trapezoids of row tiles, each packed into its own
   // output with its own leading dimension; operands and tables are the symmetric ones
   int shard; int sh_b0[2]; int sh_cnt0; T* sh_k[2]; T* sh_t[2]; int64_t sh_ld[2]; int64_t sh_cols[2];
+  // cyclic column-first shard (smn_kernel_mlp_shard_cols, shard == 2): the rank's tile rows are t_j = j P + (j even ? rank :
+  // P-1-rank), every lower tile of them, stored into the rank's chunk piece by piece (a piece = the tile columns
+  // [cy_c[g], cy_c[g+1]) of every tile row from cy_c[g] down, cy_c[g] a multiple of P): slot (j - cy_c[g]/P) of piece g is a
+  // 128 x (width of the piece) strip.  sh_k[0] / sh_t[0] are the chunk bases.
+  int cy_P, cy_rank, cy_T, cy_np; int cy_c[kMaxColPieces + 1]; int64_t cy_off[kMaxColPieces];
 };
 
 // BM = 64 (sharded f32 builds of few tiles only): two workgroups per 128x128 tile, 64 rows each -- a piece of a pipelined shard is
@@ -117,7 +124,32 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 8 && NTK) ? 1 : (BM == 64 &
   int tr, tc, half = 0;
   T* out_k = a.out_k; T* out_t = a.out_t;
   int64_t ldo = a.ldo, out_cols = a.out_cols;
-  if (a.shard) {
+  if (a.shard == 2) {
+    int idx = blockIdx.x;
+    if (BM == 64) {
+      half = idx & 1;
+      idx >>= 1;
+    }
+    int j = 0, t = a.cy_rank;                  // tile row t_j holds t_j + 1 lower tiles (none when it lies past the kernel)
+    while (true) {
+      const int cnt = t < a.cy_T ? t + 1 : 0;
+      if (idx < cnt) break;
+      idx -= cnt;
+      ++j;
+      t = j * a.cy_P + ((j & 1) ? a.cy_P - 1 - a.cy_rank : a.cy_rank);
+      if (j * a.cy_P >= a.cy_T) return;        // (grid padding; uniform per workgroup)
+    }
+    tr = t;
+    tc = idx;
+    int g = 0;
+    while (g + 1 < a.cy_np && tc >= a.cy_c[g + 1]) ++g;
+    ldo = (int64_t)(a.cy_c[g + 1] - a.cy_c[g]) * kTile;
+    out_cols = a.out_cols;
+    // strip of slot j - c_g / P: local row (gr - t*128), local column (gc - c_g*128); shifts folded into the base pointers
+    const int64_t shift = a.cy_off[g] + ((int64_t)(j - a.cy_c[g] / a.cy_P) - t) * kTile * ldo - (int64_t)a.cy_c[g] * kTile;
+    out_k = a.sh_k[0] ? a.sh_k[0] + shift : nullptr;
+    out_t = a.sh_t[0] ? a.sh_t[0] + shift : nullptr;
+  } else if (a.shard) {
     int idx = blockIdx.x;
     if (BM == 64) {
       half = idx & 1;
@@ -461,46 +493,22 @@ int launch_build_t(smn_ctx* ctx, const BuildArgs<T>& a, int64_t ntiles, size_t l
     lds = std::max<size_t>(TileNT<T, 64, kTile, SMN_STAGES>::LDS_BYTES, (size_t)(a.prog.nsets * 2 + 1) * 2 * kTile * sizeof(T));
   }
   SMN_TRY(smn_allow_lds(ctx, reinterpret_cast<const void*>(kern), lds));
-  // A sharded build beside a live exchange (communicator of more than one rank, or SMN_COMM_CUS_FORCE for rehearsals) goes to
-  // the stream whose CU mask leaves comm_cus CUs alone: RCCL's all-gather is a kernel too, and behind a build that fills every
-  // CU with two workgroups it would only run as the build drains -- the exposed exchange would be the whole exchange, not the
-  // last piece.  Same order as on the main stream (an event either side).
-  const bool masked = a.shard && ctx->stream_build && ctx->comm_cus > 0 && ((ctx->comm && ctx->nranks > 1) || ctx->comm_cus_force);
-  // Inside a pipelined exchange (smn_shard_begin ... smn_lml_from_shards) the pieces rotate over the build streams
-  // and the main stream does not wait for them one by one: whoever consumes a piece waits for it (smn_shard_exchange_part
-  // makes the communication stream wait for ev_bd, smn_lml_from_shards / smn_shard_wait the main stream).  Anywhere else
-  // the build joins the main stream at once, as a launch on it would.
-  const bool piecewise = masked && ctx->shard_a != nullptr && ctx->n_build_streams > 1;
-  const int bi = piecewise ? (int)(ctx->build_seq++ % (unsigned)ctx->n_build_streams) : 0;
-  hipStream_t st = masked ? (bi ? ctx->stream_bx[bi - 1] : ctx->stream_build) : ctx->stream;
-  if (masked) {
-    SMN_HIP(ctx, hipEventRecord(ctx->ev_b0, ctx->stream));
-    SMN_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_b0, 0));
-  }
   {
-    ProfScope ps(ctx, PROF_BUILD, st);
-    hipLaunchKernelGGL(kern, dim3((unsigned)ntiles), dim3(256), lds, st, a);
+    ProfScope ps(ctx, PROF_BUILD, ctx->stream);
+    hipLaunchKernelGGL(kern, dim3((unsigned)ntiles), dim3(256), lds, ctx->stream, a);
   }
   SMN_CHECK_LAUNCH(ctx);
-  if (piecewise) {
-    SMN_HIP(ctx, hipEventRecord(ctx->ev_bd[bi], st));
-    ctx->builds_pending |= 1u << bi;
-  } else if (masked) {
-    SMN_HIP(ctx, hipEventRecord(ctx->ev_b1, st));
-    SMN_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_b1, 0));
-  }
   return SMN_OK;
 }
 
 template <typename T, int NET, int ACT>
 int launch_build_n(smn_ctx* ctx, const BuildArgs<T>& a, int64_t ntiles, size_t lds, bool ntk) {
   if constexpr (sizeof(T) == 4) {
-    // f32 launches of few tiles (pieces of a pipelined shard, a rank's share of the build, small kernels): 64-row half tiles.  Measured per rank on
-    // 240 CUs (profiles/r03_shard_pieces_probe.json): 11-17 % faster for pieces of 260-520 tiles (the default pieces at 2, 4 and 8
-    // GPUs), a few % either way around 1000 tiles; the un-sharded 8392-tile build of one GPU is 5 % SLOWER with them (6.97 against
-    // 6.6 ms) and so are the eight 1032-tile pieces of the one-rank rehearsal: launches above 600 tiles keep the 128-row tile.
-    // (un-sharded launches too, from 64 tiles on: C2's 528-tile build 0.144 -> 0.118 ms; below that nothing to balance)
-    if (ntiles <= ctx->shard_half_tiles_max && (a.shard || ntiles >= 64)) {
+    // f32 launches of few tiles (a rank's share of a sharded build, small kernels): 64-row half tiles.  Measured per rank
+    // (profiles/r03_shard_pieces_probe.json): 11-17 % faster for launches of 260-520 tiles, a few % either way around 1000 tiles;
+    // the un-sharded 8392-tile build of one GPU is 5 % SLOWER with them (6.97 against 6.6 ms): launches above kHalfTileBuildMax
+    // keep the 128-row tile.  (Un-sharded launches too, from 64 tiles on: C2's 528-tile build 0.144 -> 0.118 ms.)
+    if (ntiles <= kHalfTileBuildMax && (a.shard || ntiles >= 64)) {
       if (!a.shard) ntiles = (ntiles + 7) / 8 * 8;   // the un-sharded decode pairs the halves inside groups of 16 workgroups
       return ntk ? launch_build_t<T, NET, ACT, true, 64>(ctx, a, ntiles, lds)
                  : launch_build_t<T, NET, ACT, false, 64>(ctx, a, ntiles, lds);
@@ -565,7 +573,20 @@ int run_build_t(smn_ctx* ctx, const BuildCall& c) {
   a.use_map = 0;
   a.map = TileMap::make(tm, tn, c.symmetric);
   a.shard = c.shard;
-  if (c.shard) {
+  if (c.shard == 2) {
+    if (!c.symmetric) return smn_fail(ctx, SMN_EINVAL, "run_build: shard mode needs the symmetric operands");
+    a.cy_P = c.cy_P; a.cy_rank = c.cy_rank; a.cy_T = (int)tm; a.cy_np = c.cy_np;
+    for (int g = 0; g <= c.cy_np; ++g) a.cy_c[g] = (int)c.cy_c[g];
+    for (int g = 0; g < c.cy_np; ++g) a.cy_off[g] = c.cy_off[g];
+    a.sh_k[0] = (c.get_mask & SMN_GET_NNGP) ? static_cast<T*>(c.shard_k[0]) : nullptr;
+    a.sh_t[0] = ntk ? static_cast<T*>(c.shard_t[0]) : nullptr;
+    ntiles = 0;
+    for (int64_t j = 0; j * c.cy_P < tm; ++j) {
+      const int64_t t = j * c.cy_P + ((j & 1) ? c.cy_P - 1 - c.cy_rank : c.cy_rank);
+      if (t < tm) ntiles += t + 1;
+    }
+    if (ntiles == 0) return SMN_OK;
+  } else if (c.shard) {
     if (!c.symmetric) return smn_fail(ctx, SMN_EINVAL, "run_build: shard mode needs the symmetric operands");
     int64_t cnt[2] = {0, 0};
     for (int w = 0; w < 2; ++w) {
@@ -668,7 +689,7 @@ int recursion_t(smn_ctx* ctx, const BuildSpec& spec, const void* k0, int64_t n1,
     return smn_fail(ctx, SMN_EINVAL, "smn_recursion: k0/out must be 16-byte aligned with ld %% %d == 0", (int)(16 / sizeof(T)));
   constexpr int TS = 64;
   const int64_t t1 = (n1 + TS - 1) / TS, t2 = (n2 + TS - 1) / TS;
-  const bool lower = symmetric && n1 == n2 && ctx->rec_sym;   // SMN_REC_SYM=0: the symmetric input as a rectangle too (A/B)
+  const bool lower = symmetric && n1 == n2;
   const int64_t ntiles = lower ? t1 * (t1 + 1) / 2 : t1 * t2;
   if (ntiles >= (int64_t)INT32_MAX) return smn_fail(ctx, SMN_ENOTSUP, "smn_recursion: too many tiles");
   a.sym_tiles = lower ? 1 : 2;
@@ -814,37 +835,27 @@ extern "C" int smn_kernel_mlp_lower_rows(smn_ctx* ctx, int dtype, int net, int a
                       nngp_rows_d, ntk_rows_d, ldk, nullptr, nullptr, true);
 }
 
-// Tile rows [lo_t0, lo_t1) of this rank's low block and [hi_t0, hi_t1) of its high block (128-row tiles counted from
-// the block's first row), written into the rank's packed chunk.  reuse_operand != 0: the padded copy of x and its row
-// norms left in the workspace by the previous shard call of this context are used as they are (same x, n, d) -- the
-// pieces of one pipelined build pad once.
-static int shard_rows(smn_ctx* ctx, int dtype, int net, int act, int num_hiddens, double w_std, double b_std,
-                      double last_w_std, const void* x_d, int64_t n, int64_t ldx, int64_t d, int nranks, int rank,
-                      int64_t block_rows, int64_t lo_t0, int64_t lo_t1, int64_t hi_t0, int64_t hi_t1, int reuse_operand,
-                      int get_mask, void* nngp_chunk_d, void* ntk_chunk_d) {
+// One rank's whole share of the paired layout: the lower trapezoids of row blocks `rank` and 2 nranks - 1 - rank, packed
+// into the rank's chunk (low block first).
+extern "C" int smn_kernel_mlp_shard(smn_ctx* ctx, int dtype, int net, int act, int num_hiddens, double w_std,
+                                    double b_std, double last_w_std, const void* x_d, int64_t n, int64_t ldx,
+                                    int64_t d, int nranks, int rank, int64_t block_rows, int get_mask,
+                                    void* nngp_chunk_d, void* ntk_chunk_d) {
+  SMN_TRY(check_common(ctx, dtype, n, 1, d));
+  SMN_ENTER(ctx);
   if (nranks <= 0 || rank < 0 || rank >= nranks || block_rows <= 0 || block_rows % kTile ||
       2 * (int64_t)nranks * block_rows < n)
     return smn_fail(ctx, SMN_EINVAL, "smn_kernel_mlp_shard: bad geometry (n=%lld ranks=%d rank=%d block_rows=%lld)",
                     (long long)n, nranks, rank, (long long)block_rows);
   if (!x_d || ((get_mask & SMN_GET_NNGP) && !nngp_chunk_d) || ((get_mask & SMN_GET_NTK) && !ntk_chunk_d))
     return smn_fail(ctx, SMN_EINVAL, "smn_kernel_mlp_shard: null pointer");
-  const int64_t tpb = block_rows / kTile;
-  if (lo_t0 < 0 || lo_t1 > tpb || lo_t0 > lo_t1 || hi_t0 < 0 || hi_t1 > tpb || hi_t0 > hi_t1)
-    return smn_fail(ctx, SMN_EINVAL, "smn_kernel_mlp_shard_rows: tile rows [%lld,%lld) / [%lld,%lld) of %lld per block",
-                    (long long)lo_t0, (long long)lo_t1, (long long)hi_t0, (long long)hi_t1, (long long)tpb);
   const size_t es = dtype_size(dtype);
   const int64_t kp = k_pad(dtype, d), r1 = round_up(n, kTile), h = block_rows;
   void* xs = nullptr;
-  const size_t xbytes = es * (size_t)kp * (size_t)r1 + sizeof(double) * (size_t)r1;
-  const bool prepared = ctx->op_x == x_d && ctx->op_n == n && ctx->op_d == d && ctx->op_ldx == ldx && ctx->op_dtype == dtype &&
-                        ctx->ws_bytes[0] >= xbytes;
-  if (reuse_operand && !prepared)
-    return smn_fail(ctx, SMN_EINVAL, "smn_kernel_mlp_shard_rows: reuse_operand, but slot 0 does not hold the padded copy of this x");
-  SMN_TRY(smn_workspace(ctx, 0, xbytes, &xs));   // (clears the tag: set again below)
+  SMN_TRY(smn_workspace(ctx, 0, es * (size_t)kp * (size_t)r1 + sizeof(double) * (size_t)r1, &xs));
   double* q1 = static_cast<double*>(xs);
   char* x1p = reinterpret_cast<char*>(q1 + r1);
-  if (!reuse_operand) SMN_TRY(pad_rows(ctx, dtype, x_d, n, ldx, d, x1p, r1, kp, q1));
-  ctx->op_x = x_d; ctx->op_n = n; ctx->op_d = d; ctx->op_ldx = ldx; ctx->op_dtype = dtype;
+  SMN_TRY(pad_rows(ctx, dtype, x_d, n, ldx, d, x1p, r1, kp, q1));
   BuildCall c{};
   c.spec = BuildSpec{dtype, net, act, num_hiddens, w_std, b_std, last_w_std};
   c.kp = (int)kp; c.d = d; c.get_mask = get_mask;
@@ -854,43 +865,74 @@ static int shard_rows(smn_ctx* ctx, int dtype, int net, int act, int num_hiddens
   c.store_mode = STORE_BOUNDS; c.out_rows = n; c.out_cols = n;
   c.shard = 1;
   const int64_t blk[2] = {rank, 2 * (int64_t)nranks - 1 - rank};
-  const int64_t t0[2] = {lo_t0, hi_t0}, t1[2] = {lo_t1, hi_t1};
   for (int w = 0; w < 2; ++w) {
     const int64_t ld = (blk[w] + 1) * h;
-    int64_t rb = blk[w] * h + t0[w] * kTile, re = blk[w] * h + t1[w] * kTile;
+    int64_t rb = blk[w] * h, re = blk[w] * h + h;
     if (rb > n) rb = n;
     if (re > n) re = n;
     c.shard_rb[w] = rb;
     c.shard_re[w] = re;
     c.shard_ld[w] = ld;
-    // low block first, then the high one; inside a block the rows of the range start t0 tile rows down
-    const size_t off = es * (size_t)((w == 0 ? 0 : h * (rank + 1) * h) + t0[w] * kTile * ld);
+    const size_t off = es * (size_t)(w == 0 ? 0 : h * (rank + 1) * h);   // low block first, then the high one
     c.shard_k[w] = nngp_chunk_d ? static_cast<char*>(nngp_chunk_d) + off : nullptr;
     c.shard_t[w] = ntk_chunk_d ? static_cast<char*>(ntk_chunk_d) + off : nullptr;
   }
   return run_build(ctx, c);
 }
 
-extern "C" int smn_kernel_mlp_shard(smn_ctx* ctx, int dtype, int net, int act, int num_hiddens, double w_std,
-                                    double b_std, double last_w_std, const void* x_d, int64_t n, int64_t ldx,
-                                    int64_t d, int nranks, int rank, int64_t block_rows, int get_mask,
-                                    void* nngp_chunk_d, void* ntk_chunk_d) {
-  SMN_TRY(check_common(ctx, dtype, n, 1, d));
-  SMN_ENTER(ctx);
-  const int64_t tpb = block_rows > 0 ? block_rows / kTile : 0;
-  return shard_rows(ctx, dtype, net, act, num_hiddens, w_std, b_std, last_w_std, x_d, n, ldx, d, nranks, rank, block_rows,
-                    0, tpb, 0, tpb, 0, get_mask, nngp_chunk_d, ntk_chunk_d);
+int col_pieces_make(smn_ctx* ctx, int64_t n, int nranks, int npieces, const int64_t* piece_cols, ColPieces* out) {
+  if (n <= 0 || nranks <= 0 || npieces <= 0 || npieces > kMaxColPieces || !piece_cols)
+    return smn_fail(ctx, SMN_EINVAL, "column pieces: n=%lld ranks=%d pieces=%d (at most %d)", (long long)n, nranks, npieces, kMaxColPieces);
+  ColPieces cp;
+  cp.P = nranks; cp.np = npieces; cp.T = (n + kTile - 1) / kTile;
+  for (int g = 0; g <= npieces; ++g) cp.c[g] = piece_cols[g];
+  if (cp.c[0] != 0 || cp.c[npieces] != cp.T)
+    return smn_fail(ctx, SMN_EINVAL, "column pieces must span the tile columns [0, %lld)", (long long)cp.T);
+  for (int g = 0; g < npieces; ++g) {
+    if (cp.c[g + 1] <= cp.c[g] || cp.c[g] % nranks)
+      return smn_fail(ctx, SMN_EINVAL, "column piece %d = [%lld, %lld): boundaries must ascend in multiples of the %d ranks", g,
+                      (long long)cp.c[g], (long long)cp.c[g + 1], nranks);
+    cp.off[g + 1] = cp.off[g] + cp.count(g);
+  }
+  *out = cp;
+  return SMN_OK;
 }
 
-extern "C" int smn_kernel_mlp_shard_rows(smn_ctx* ctx, int dtype, int net, int act, int num_hiddens, double w_std,
+// One rank's whole share of the cyclic column-first layout (internal.hpp ColPieces) in ONE launch on every CU: all lower
+// tiles of its tile rows, stored piece by piece into its chunk, ready for smn_shard_exchange_cols.
+extern "C" int smn_kernel_mlp_shard_cols(smn_ctx* ctx, int dtype, int net, int act, int num_hiddens, double w_std,
                                          double b_std, double last_w_std, const void* x_d, int64_t n, int64_t ldx,
-                                         int64_t d, int nranks, int rank, int64_t block_rows, int64_t lo_t0,
-                                         int64_t lo_t1, int64_t hi_t0, int64_t hi_t1, int reuse_operand, int get_mask,
-                                         void* nngp_chunk_d, void* ntk_chunk_d) {
+                                         int64_t d, int nranks, int rank, int npieces, const int64_t* piece_cols,
+                                         int get_mask, void* nngp_chunk_d, void* ntk_chunk_d) {
   SMN_TRY(check_common(ctx, dtype, n, 1, d));
   SMN_ENTER(ctx);
-  return shard_rows(ctx, dtype, net, act, num_hiddens, w_std, b_std, last_w_std, x_d, n, ldx, d, nranks, rank, block_rows,
-                    lo_t0, lo_t1, hi_t0, hi_t1, reuse_operand, get_mask, nngp_chunk_d, ntk_chunk_d);
+  if (rank < 0 || rank >= nranks) return smn_fail(ctx, SMN_EINVAL, "smn_kernel_mlp_shard_cols: rank %d of %d", rank, nranks);
+  if (!x_d || !(get_mask & (SMN_GET_NNGP | SMN_GET_NTK)) || ((get_mask & SMN_GET_NNGP) && !nngp_chunk_d) ||
+      ((get_mask & SMN_GET_NTK) && !ntk_chunk_d))
+    return smn_fail(ctx, SMN_EINVAL, "smn_kernel_mlp_shard_cols: null pointer or empty get mask");
+  ColPieces cp;
+  SMN_TRY(col_pieces_make(ctx, n, nranks, npieces, piece_cols, &cp));
+  const size_t es = dtype_size(dtype);
+  const int64_t kp = k_pad(dtype, d), r1 = round_up(n, kTile);
+  void* xs = nullptr;
+  SMN_TRY(smn_workspace(ctx, 0, es * (size_t)kp * (size_t)r1 + sizeof(double) * (size_t)r1, &xs));
+  double* q1 = static_cast<double*>(xs);
+  char* x1p = reinterpret_cast<char*>(q1 + r1);
+  SMN_TRY(pad_rows(ctx, dtype, x_d, n, ldx, d, x1p, r1, kp, q1));
+  BuildCall c{};
+  c.spec = BuildSpec{dtype, net, act, num_hiddens, w_std, b_std, last_w_std};
+  c.kp = (int)kp; c.d = d; c.get_mask = get_mask;
+  c.x1p = x1p; c.ld1 = kp; c.rows1 = r1; c.q1 = q1;
+  c.x2p = x1p; c.ld2 = kp; c.rows2 = r1; c.q2 = q1;
+  c.symmetric = 1; c.mirror = 0; c.exact_diag = 1;
+  c.store_mode = STORE_BOUNDS; c.out_rows = n; c.out_cols = n;
+  c.shard = 2;
+  c.cy_P = nranks; c.cy_rank = rank; c.cy_np = npieces;
+  for (int g = 0; g <= npieces; ++g) c.cy_c[g] = cp.c[g];
+  for (int g = 0; g < npieces; ++g) c.cy_off[g] = cp.off[g];
+  c.shard_k[0] = nngp_chunk_d;
+  c.shard_t[0] = ntk_chunk_d;
+  return run_build(ctx, c);
 }
 
 extern "C" int smn_gram(smn_ctx* ctx, int dtype, const void* x1_d, int64_t n1, int64_t ldx1, const void* x2_d,

@@ -1,9 +1,16 @@
-"""Row-block sharding of the kernel build across the GPUs of one node.
+"""Sharding of the kernel build across the GPUs of one node.
 
-Every K entry depends only on (x_i, x_j, q_i, q_j), so rows are independent units: rank r of P owns the
-row block [r*R, min(n, (r+1)*R)) with R = ceil(n / P), X is replicated, and ONE all-gather of equal-sized
-chunks (R * ld elements per rank, the last one zero-padded) assembles K.  Pure host logic: no device calls
-here, so the same functions drive the RCCL path (bench.py) and the gloo CPU tests.
+Every K entry depends only on (x_i, x_j, q_i, q_j), so rows are independent units and X is replicated.  Three layouts, from
+plain to what `bench.py --gpus P` runs:
+
+* full row blocks (`row_shard`): rank r owns rows [r*R, (r+1)*R) x all columns; one all-gather of R*ld elements per rank;
+* paired lower blocks (`paired_blocks`): 2P row blocks, rank r owns blocks r and 2P-1-r, lower trapezoids only -- half the
+  flops and bytes, exactly balanced; one monolithic all-gather, then the factorisation;
+* cyclic column-first (`col_layout`, `lml_sharded_cols`): 128-row tile rows dealt in boustrophedon order, lower tiles only;
+  every rank holds an equal share of EVERY column range, so the exchange goes out column range by column range and the
+  single-GPU factorisation starts on the first super-panel's columns while the rest is still on the links.
+
+Pure host logic: no device calls here, so the same functions drive the RCCL path (bench.py) and the gloo CPU tests.
 """
 from __future__ import annotations
 
@@ -122,54 +129,81 @@ def _check_communicator(ctx, world):
                            % (world, nr.value))
 
 
-# ------------------------------------------------------------------ pipelined exchange (pieces of the chunks)
-# The all-gather rides behind the build: a rank's chunk is cut into `parts` equal element ranges; as soon as the rank has
-# built the tile rows that complete piece g, piece g of ALL ranks is gathered (and scattered into the factorisation
-# workspace) on the communication stream while the tile rows of piece g+1 are being built.  What remains exposed is the
-# last piece.  Host logic only; the device steps go through a backend object so that the gloo CPU tests drive exactly
-# this control flow.
+# ------------------------------------------------------------------ cyclic column-first layout
+# The factorisation is right-looking: its first super-panel needs only the kernel's first 1024 COLUMNS (all rows), the
+# update that follows the next 1024, and so on.  Row-block shards deliver whole rows, i.e. every column range last.  Here the
+# 128-row tile rows are dealt in boustrophedon order with period 2P -- group j = tile rows [jP, (j+1)P), rank r owns
+# t_j(r) = jP + (r if j is even else P-1-r) -- so that (i) tile row t holds t+1 lower tiles and every pair of groups gives
+# every rank the same number of them: the build is balanced; (ii) every aligned group of P tile rows holds exactly one tile
+# row per rank: a tile-column range [c0, c1) with c0 a multiple of P is ceil((T - c0)/P) strips of 128 x (c1-c0)*128
+# elements on EVERY rank, one equal-count all-gather.  (Tile rows that start inside the range carry their above-diagonal
+# tiles as padding: 5.8 % of the bytes at N = 16384, P = 8.)  Mirrors csrc/internal.hpp ColPieces.
 
-def default_parts(n: int, world: int) -> int:
-    """Pieces per chunk.  A piece's tile rows are one build launch, and a launch of fewer tiles than the chip has CUs
-    leaves CUs idle for a whole tile time (0.2-0.4 ms at d = 3072): at least ~256 tiles per piece, at most 8 pieces (16 on
-    two ranks, where the exchange over the single link takes as long as the build and what is exposed is one piece of it),
-    a power of two that cuts the chunk into multiples of 4 elements."""
-    t = -(-n // TILE)
-    tiles_per_rank = t * (t + 1) // 2 // world
-    p = 16 if world == 2 else 8
-    while p > 1 and tiles_per_rank // p < 256:
-        p //= 2
-    chunk = paired_chunk_elems(n, world)
-    while p > 1 and (chunk % p or (chunk // p) % 4):
-        p //= 2
-    return p
+MAX_COL_PIECES = 16
 
 
-def part_tile_rows(n: int, world: int, rank: int, parts: int):
-    """For each piece g: (lo_t0, lo_t1, hi_t0, hi_t1) = the 128-row tile rows of the rank's low / high block that must be
-    built before piece g can be gathered and were not built for an earlier piece.  Tile rows are built whole and in
-    packed order (low block top to bottom, then the high block), so piece g needs every tile row that STARTS before the
-    piece ends."""
-    h = block_rows(n, world)
-    chunk = paired_chunk_elems(n, world)
-    if parts <= 0 or chunk % parts or (chunk // parts) % 4:
-        raise ValueError("parts=%d must divide the chunk (%d elements) into multiples of 4" % (parts, chunk))
-    piece = chunk // parts
-    tpb = h // TILE
-    lo, hi = paired_blocks(world, rank)
-    ld_lo, ld_hi = (lo + 1) * h, (hi + 1) * h
-    starts = [t * TILE * ld_lo for t in range(tpb)] + [h * ld_lo + t * TILE * ld_hi for t in range(tpb)]
-    out, built = [], 0
-    for g in range(parts):
-        end = (g + 1) * piece
-        upto = built
-        while upto < 2 * tpb and starts[upto] < end:
-            upto += 1
-        a, b = built, upto                      # packed tile rows [a, b)
-        out.append((min(a, tpb), min(b, tpb), max(a, tpb) - tpb, max(b, tpb) - tpb))
-        built = upto
-    assert built == 2 * tpb
+def tile_rows(n: int) -> int:
+    return -(-n // TILE)
+
+
+def tile_row_owner(world: int, t: int) -> int:
+    u = t % (2 * world)
+    return u if u < world else 2 * world - 1 - u
+
+
+def rank_tile_row(world: int, rank: int, j: int) -> int:
+    """The tile row rank `rank` owns in group j (may lie past the kernel: the caller compares with tile_rows(n))."""
+    return j * world + (rank if j % 2 == 0 else world - 1 - rank)
+
+
+def rank_tile_rows(n: int, world: int, rank: int):
+    t_all = tile_rows(n)
+    out = []
+    for j in range(-(-t_all // world)):
+        t = rank_tile_row(world, rank, j)
+        if t < t_all:
+            out.append(t)
     return out
+
+
+def default_col_pieces(n: int, world: int, first_cols: int = 1024, max_pieces: int = 16):
+    """Tile-column boundaries [0, c1, ..., T] of the exchange: ranges of one super-panel of the factorisation (1024
+    columns) each -- the first panel chain waits for piece 0 only, the update that follows it for piece 1, and a narrow
+    range carries little above-diagonal padding ((w-1)/(T+1) of the bytes for w tile columns: 5.4 % at N = 16384) --
+    widened so that there are at most `max_pieces` of them (N = 32768: 2048 columns, that factorisation's own first
+    super-panel).  Boundaries are multiples of `world` (equal counts on every rank)."""
+    if n <= 0 or world <= 0:
+        raise ValueError("n and world must be positive")
+    t_all = tile_rows(n)
+    up = lambda v: -(-v // world) * world          # noqa: E731
+    w = up(max(1, first_cols // TILE, -(-t_all // min(max_pieces, MAX_COL_PIECES))))
+    cols = list(range(0, t_all, w)) + [t_all]
+    return cols
+
+
+def col_layout(n: int, world: int, cols):
+    """Per piece g: slots (strips per rank), width (elements per strip row), count (elements per rank), off (element offset
+    of the piece in a rank's chunk); plus `elems` = elements per rank.  The staging buffer holds piece g of all ranks at
+    world * off[g], rank-major."""
+    t_all = tile_rows(n)
+    cols = [int(c) for c in cols]
+    if len(cols) < 2 or len(cols) - 1 > MAX_COL_PIECES or cols[0] != 0 or cols[-1] != t_all:
+        raise ValueError("column pieces must span the tile columns [0, %d) in at most %d pieces" % (t_all, MAX_COL_PIECES))
+    slots, width, count, off = [], [], [], [0]
+    for g in range(len(cols) - 1):
+        if cols[g + 1] <= cols[g] or cols[g] % world:
+            raise ValueError("piece %d = [%d, %d): boundaries must ascend in multiples of the %d ranks" % (g, cols[g], cols[g + 1], world))
+        slots.append(-(-(t_all - cols[g]) // world))
+        width.append((cols[g + 1] - cols[g]) * TILE)
+        count.append(slots[-1] * TILE * width[-1])
+        off.append(off[-1] + count[-1])
+    return {"cols": cols, "slots": slots, "width": width, "count": count, "off": off[:-1], "elems": off[-1]}
+
+
+def cols_array(cols):
+    """The boundaries as the int64 array the C-ABI takes."""
+    import ctypes as C
+    return (C.c_int64 * len(cols))(*[int(c) for c in cols])
 
 
 class DeviceBackend:
@@ -184,54 +218,54 @@ class DeviceBackend:
         self.ctx.call("smn_comm_info", C.byref(nr), C.byref(rk))
         return nr.value
 
-    def begin(self, dtype_code, n):
-        self.ctx.call("smn_shard_begin", dtype_code, n)
+    def begin(self, dtype_code, n, eps_abs):
+        self.ctx.call("smn_shard_begin", dtype_code, n, eps_abs)
 
-    def build_rows(self, dtype_code, spec, x_ptr, n, ldx, d, world, rank, h, rows, reuse, mine_ptr, ntk_mine_ptr=None):
+    def build_cols(self, dtype_code, spec, x_ptr, n, ldx, d, world, rank, cols, mine_ptr, ntk_mine_ptr=None):
         net, act, num_hiddens, w_std, b_std, last_w_std = spec
-        self.ctx.call("smn_kernel_mlp_shard_rows", dtype_code, net, act, num_hiddens, w_std, b_std, last_w_std,
-                      x_ptr, n, ldx, d, world, rank, h, rows[0], rows[1], rows[2], rows[3], 1 if reuse else 0,
+        self.ctx.call("smn_kernel_mlp_shard_cols", dtype_code, net, act, num_hiddens, w_std, b_std, last_w_std,
+                      x_ptr, n, ldx, d, world, rank, len(cols) - 1, cols_array(cols),
                       1 | (2 if ntk_mine_ptr is not None else 0), mine_ptr, ntk_mine_ptr)
 
-    def exchange_part(self, dtype_code, mine_ptr, stage_ptr, n, world, h, parts, part, ntk=None):
-        """Piece `part` of the NNGP chunks into the factorisation workspace; with ntk = (mine, stage, out, ld) also the
-        same piece of the NTK chunks into the caller's matrix `out`.  Both on the communication stream."""
-        self.ctx.call("smn_shard_exchange_part", dtype_code, mine_ptr, stage_ptr, n, world, h, parts, part)
+    def exchange_cols(self, dtype_code, mine_ptr, stage_ptr, n, world, cols, piece, ntk=None):
+        """Piece `piece` of the NNGP chunks into the factorisation workspace; with ntk = (mine, stage, out, ld) also the
+        same piece of the NTK chunks into the caller's matrix `out`."""
+        ca = cols_array(cols)
+        self.ctx.call("smn_shard_exchange_cols", dtype_code, mine_ptr, stage_ptr, n, world, len(cols) - 1, ca, piece)
         if ntk is not None:
-            self.ctx.call("smn_shard_exchange_part_to", dtype_code, ntk[0], ntk[1], n, world, h, parts, part, ntk[2], ntk[3])
+            self.ctx.call("smn_shard_exchange_cols_to", dtype_code, ntk[0], ntk[1], n, world, len(cols) - 1, ca, piece,
+                          ntk[2], ntk[3])
 
-    def lml(self, dtype_code, n, y_ptr, eps_abs, df, scale):
+    def lml(self, dtype_code, n, y_ptr, df, scale):
         import ctypes as C
         lp, quad, logdet, info = C.c_double(), C.c_double(), C.c_double(), C.c_int()
-        self.ctx.call("smn_lml_from_shards", dtype_code, n, y_ptr, eps_abs, df, scale, C.byref(lp), C.byref(quad),
+        self.ctx.call("smn_lml_from_shards", dtype_code, n, y_ptr, df, scale, C.byref(lp), C.byref(quad),
                       C.byref(logdet), C.byref(info))
         return lp.value, quad.value, logdet.value, info.value
 
 
-def lml_sharded_pipelined(backend, dtype_code, spec, x_ptr, n, ldx, d, y_ptr, rank, world, mine_ptr, stage_ptr,
-                          eps_abs, df=0.0, scale=1.0, parts=None, ntk=None):
-    """One SPR.loss evaluation with the kernel build sharded over `world` ranks and the exchange pipelined behind it
-    (`spec` = (net, act, num_hiddens, w_std, b_std, last_w_std); mine: the rank's chunk, paired_chunk_elems elements;
-    stage: world * that).  Returns (logpdf, quad, logdet, info); every rank computes the same values.
-    ntk = (mine, stage, out, ld): the build also produces the NTK (one joint launch per piece: BASELINE config 5's "erf NNGP
-    + NTK"), whose pieces ride the same pipeline and are assembled in the caller's matrix `out` (lower triangle by
-    128-column tiles) by the time the likelihood has been read."""
+def lml_sharded_cols(backend, dtype_code, spec, x_ptr, n, ldx, d, y_ptr, rank, world, mine_ptr, stage_ptr,
+                     eps_abs, df=0.0, scale=1.0, cols=None, ntk=None, progress=None):
+    """One SPR.loss evaluation with the kernel build sharded over `world` ranks in the cyclic column-first layout
+    (`spec` = (net, act, num_hiddens, w_std, b_std, last_w_std); mine: the rank's chunk, col_layout(...)["elems"] elements;
+    stage: world * that).  The rank builds its whole share in one launch; the pieces then go out column range by column
+    range (all-gather + scatter on the context's side streams) and the factorisation, issued right behind them, waits for
+    each piece only when it reaches its columns.  Returns (logpdf, quad, logdet, info); every rank computes the same values.
+    ntk = (mine, stage, out, ld): the build also produces the NTK (one joint launch: BASELINE config 5's "erf NNGP + NTK"),
+    whose pieces ride the same streams and are assembled in the caller's matrix `out` (lower triangle by 128-column tiles)
+    by the time the likelihood has been read.  progress(phase): called with a short phase name before every step (the
+    watchdog of bench.py)."""
     if backend.comm_size() != world:
         raise RuntimeError("sharded build over %d ranks, but the communicator has %d (smn_comm_init first)"
                            % (world, backend.comm_size()))
-    parts = parts or default_parts(n, world)
-    h = block_rows(n, world)
-    backend.begin(dtype_code, n)
-    padded = False
-    for g, rows in enumerate(part_tile_rows(n, world, rank, parts)):
-        if rows[1] > rows[0] or rows[3] > rows[2]:
-            if ntk is None:
-                backend.build_rows(dtype_code, spec, x_ptr, n, ldx, d, world, rank, h, rows, padded, mine_ptr)
-            else:
-                backend.build_rows(dtype_code, spec, x_ptr, n, ldx, d, world, rank, h, rows, padded, mine_ptr, ntk[0])
-            padded = True
-        if ntk is None:
-            backend.exchange_part(dtype_code, mine_ptr, stage_ptr, n, world, h, parts, g)
-        else:
-            backend.exchange_part(dtype_code, mine_ptr, stage_ptr, n, world, h, parts, g, ntk)
-    return backend.lml(dtype_code, n, y_ptr, eps_abs, df, scale)
+    cols = list(cols) if cols is not None else default_col_pieces(n, world)
+    say = progress or (lambda phase: None)
+    say("begin")
+    backend.begin(dtype_code, n, eps_abs)
+    say("build")
+    backend.build_cols(dtype_code, spec, x_ptr, n, ldx, d, world, rank, cols, mine_ptr, None if ntk is None else ntk[0])
+    for g in range(len(cols) - 1):
+        say("gather %d/%d" % (g, len(cols) - 1))
+        backend.exchange_cols(dtype_code, mine_ptr, stage_ptr, n, world, cols, g, ntk)
+    say("factor")
+    return backend.lml(dtype_code, n, y_ptr, df, scale)

@@ -110,22 +110,19 @@ def test_launcher_ends_the_other_ranks_when_one_fails(tmp_path):
 
 
 def test_ranks_agree_on_a_failed_communicator_and_fall_back_to_the_file_rendezvous(tmp_path):
-    """If smn_comm_init fails on ANY rank (no RCCL, no peer access), every rank must learn it and run as a replica, with
-    the barrier and the max over ranks going through files: two processes, rank 1 reports a failed communicator."""
-    code = "\n".join([
-        "import sys, json", "sys.path.insert(0, %r)" % ROOT, "sys.argv = ['bench.py']", "import bench",
-        "rank = int(sys.argv[1]) if len(sys.argv) > 1 else 0",
-    ])
+    """If smn_comm_init fails on ANY rank (no RCCL, no peer access), every rank must learn it; with
+    --allow-replica-fallback the barrier and the max over ranks then go through files: two processes, rank 1 reports a
+    failed communicator."""
     worker = tmp_path / "w.py"
     worker.write_text("\n".join([
         "import sys, json", "sys.path.insert(0, %r)" % ROOT, "rank = int(sys.argv[1]); sys.argv = ['bench.py']", "import bench",
-        "ok, d = bench.agree_on_communicator(%r, 2, rank, ok=(rank == 0), timeout_s=60)" % str(tmp_path / "rdv"),
+        "d = %r" % str(tmp_path / "rdv.run"),
+        "ok = bench.agree_on_communicator(d, 2, rank, ok=(rank == 0), timeout_s=60)",
         "s = bench.FileSync(d, 2, rank)",
         "s.barrier()",
         "m = s.max(10.0 + rank)",
         "g = s.gather(float(rank))",
         "print(json.dumps(dict(ok=ok, max=m, gather=g)))"]))
-    del code
     procs = [subprocess.Popen([sys.executable, str(worker), str(r)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
              for r in range(2)]
     outs = [p.communicate(timeout=120) for p in procs]
@@ -133,3 +130,81 @@ def test_ranks_agree_on_a_failed_communicator_and_fall_back_to_the_file_rendezvo
     for o in outs:
         got = json.loads(o[0].strip().splitlines()[-1])
         assert got == {"ok": False, "max": 11.0, "gather": [0.0, 1.0]}
+
+
+def test_stale_rendezvous_files_of_an_earlier_run_are_not_read(tmp_path):
+    """A file older than the process that started the ranks belongs to an earlier run (same port, recycled parent PID): the id,
+    the status flags and the file-rendezvous values are all read through _read_fresh, which treats it as absent."""
+    sys.path.insert(0, ROOT)
+    import time
+
+    import bench
+    f = tmp_path / "init_1"
+    f.write_text("1")
+    assert bench._read_fresh(str(f)) == "1"
+    old = bench._launcher_start_time() - 100.0
+    os.utime(str(f), (old, old))
+    assert bench._read_fresh(str(f)) is None
+    assert bench._read_fresh(str(tmp_path / "missing")) is None
+    # exchange_rccl_id: a non-zero rank does not take a stale id for the run's
+    stale = tmp_path / "rccl_id"
+    stale.write_bytes(bytes(128))
+    os.utime(str(stale), (old, old))
+    t0 = time.time()
+    try:
+        bench.exchange_rccl_id(None, str(stale), 1, timeout_s=0.3)
+        raised = False
+    except RuntimeError:
+        raised = True
+    assert raised and time.time() - t0 < 5
+
+
+def test_watchdog_names_the_stuck_rank_and_its_phase_in_one_json_line(tmp_path):
+    """Two ranks under the built-in launcher; rank 1 stops making progress in a named phase (as a rank stuck inside RCCL would:
+    its main thread sits in a C call, the watchdog thread keeps running).  Within the stall limit the run ends with status
+    3 and ONE JSON line on stdout that names rank 1 and the phase; nothing is left running."""
+    stub = tmp_path / "fake_bench.py"
+    stub.write_text("\n".join([
+        "import os, sys, time",
+        "sys.path.insert(0, %r)" % ROOT,
+        "import bench",
+        "if 'RANK' not in os.environ:",
+        "    bench.launch_ranks(bench.parse())",
+        "rank = int(os.environ['RANK'])",
+        "rdv = sys.argv[sys.argv.index('--rendezvous-file') + 1]",
+        "out = bench._JsonOut()",
+        "wd = bench.Watchdog(rdv + '.run', rank, 2, out)",
+        "if rank == 1:",
+        "    wd.phase('step 2: gather 3/16')",
+        "    time.sleep(600)",
+        "for k in range(6000):",
+        "    wd.phase('step %d: factor' % k)",
+        "    time.sleep(0.1)",
+    ]))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env.update(SMN_BENCH_STALL_S="3", SMN_BENCH_RANK_TIMEOUT_S="60")
+    import time
+    t0 = time.time()
+    r = subprocess.run([sys.executable, str(stub), "--gpus", "2"], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 3 and time.time() - t0 < 40, (r.returncode, r.stderr)
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    got = json.loads(lines[0])
+    assert got["stuck_rank"] == 1 and got["phase"] == "step 2: gather 3/16" and got["value"] is None and got["n_gpus"] == 2
+    assert "no progress" in got["error"] and got["ranks"]["0"]["phase"].startswith("step ")
+
+
+def test_watchdog_overall_limit_and_a_rank_that_never_started(tmp_path):
+    """diagnose(): a rank without a heartbeat file is the one named; the overall limit ends a run whose ranks all keep moving."""
+    sys.path.insert(0, ROOT)
+    import time
+
+    import bench
+    d = tmp_path / "run"
+    d.mkdir()
+    (d / "hb_0").write_text(json.dumps({"phase": "smn_comm_init", "t_phase": time.time() - 5, "t": time.time()}))
+    got = bench.diagnose(str(d), 2, "test")
+    assert got["stuck_rank"] == 1 and "never started" in got["phase"] and got["ranks"]["0"]["phase"] == "smn_comm_init"
+    (d / "hb_1").write_text(json.dumps({"phase": "done", "t_phase": time.time() - 9, "t": time.time()}))
+    got = bench.diagnose(str(d), 2, "test")
+    assert got["stuck_rank"] == 0 and got["phase"] == "smn_comm_init"        # a finished rank is never the stuck one

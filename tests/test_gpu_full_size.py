@@ -133,6 +133,19 @@ def test_c4_fused_unfused_and_sharded_routes_and_permutation_invariance(L, ctx, 
     ctx.call("smn_lml", L.F32, k.ptr, n, n, y.ptr, eps, 0.0, 1.0, C.byref(lp), C.byref(quad), C.byref(logdet), C.byref(info))
     assert info.value == 0
     assert abs(lp.value - fused[0]) < 1e-6 * abs(fused[0]) and abs(logdet.value - fused[2]) < 1e-6 * abs(fused[2])
+    del stage, k
+    # 8 ranks played on one GPU in the cyclic column-first layout (what bench.py --gpus 8 runs): one build launch per rank, the
+    # pieces scattered into the factorisation workspace, the factorisation waiting piece by piece -- the fused result bit for bit
+    from _played import play_ranks
+    cols = S.default_col_pieces(n, world)
+    stage, _ = play_ranks(L, ctx, (L.NET_MLP, L.ACT["relu"], 4, 1.0, 1e-8, 1.0), x, n, d, world, cols, with_ntk=False)
+    ca = S.cols_array(cols)
+    ctx.call("smn_shard_begin", L.F32, n, eps)
+    for g in range(len(cols) - 1):
+        ctx.call("smn_shard_scatter_cols", L.F32, stage.ptr, n, world, len(cols) - 1, ca, g, None, 0)
+    ctx.call("smn_lml_from_shards", L.F32, n, y.ptr, 0.0, 1.0, C.byref(lp), C.byref(quad), C.byref(logdet), C.byref(info))
+    assert info.value == 0 and (lp.value, quad.value, logdet.value) == fused
+    del stage
     # the LML does not depend on the order of the data points
     perm = np.random.default_rng(3).permutation(n)
     xp = ctx.to_device(c4["xh"][perm]); yp = ctx.to_device(c4["yh"][perm])

@@ -137,8 +137,7 @@ def test_gram_then_recursion_equals_fused(L, ctx, dtype):
 @pytest.mark.parametrize("net,act,layers", [("mlp", "relu", 4), ("mlp", "erf", 2), ("resnet", "relu", 2)])
 def test_symmetric_recursion_lower_tiles_and_mirror(L, ctx, dtype, n, net, act, layers):
     """smn_recursion on a symmetric K0 (find.py's sweep form): the lower-tile + LDS-mirror kernel must fill BOTH
-    triangles, match the oracle, be exactly symmetric, and agree with the row-streaming kernel it replaces."""
-    import os
+    triangles, match the oracle, be exactly symmetric, and agree with the cross form of the same kernel."""
     rng = np.random.default_rng(n)
     d, ld = 24, (n + 3) // 4 * 4                                         # 16-byte aligned rows (API contract)
     xh = rng.standard_normal((n, d)).astype(dtype)
@@ -147,30 +146,26 @@ def test_symmetric_recursion_lower_tiles_and_mirror(L, ctx, dtype, n, net, act, 
     ofn = O.mlp_kernel if net == "mlp" else O.dense_resnet_kernel
     rk, rt = ofn(xh.astype(np.float64), None, layers, act, 1.2, 0.3, 0.9, ("nngp", "ntk"))
     got = {}
-    for sym in ("1", "0"):
-        os.environ["SMN_REC_SYM"] = sym
-        try:
-            c = L.Context(0)                                                 # the flag is read at context creation
-        finally:
-            del os.environ["SMN_REC_SYM"]
-        x = c.to_device(xh)
-        k0 = c.empty((n, ld), dtype); q = c.empty((n,), dtype)
-        c.call("smn_gram", code, x.ptr, n, d, None, 0, 0, d, k0.ptr, ld, q.ptr, None)
+    c = ctx
+    x = c.to_device(xh)
+    k0 = c.empty((n, ld), dtype); q = c.empty((n,), dtype)
+    c.call("smn_gram", code, x.ptr, n, d, None, 0, 0, d, k0.ptr, ld, q.ptr, None)
+    for sym in (1, 0):                 # symmetric = 0: the same K0 through the cross form (every tile of the square, no mirror)
         k = c.to_device(np.full((n, ld), np.nan, dtype)); t = c.to_device(np.full((n, ld), np.nan, dtype))
         c.call("smn_recursion", code, netc, L.ACT[act], layers, 1.2, 0.3, 0.9, k0.ptr, n, n, ld, q.ptr, q.ptr,
-               1, L.GET_NNGP | L.GET_NTK, k.ptr, t.ptr, ld)
+               sym, L.GET_NNGP | L.GET_NTK, k.ptr, t.ptr, ld)
         got[sym] = (k.numpy()[:, :n], t.numpy()[:, :n])
         assert relerr(got[sym][0], rk) < RTOL[dtype] and relerr(got[sym][1], rt) < RTOL[dtype] * 5
         k1 = c.to_device(np.full((n, ld), np.nan, dtype))                    # NNGP only (the f32 ReLU fast path)
         c.call("smn_recursion", code, netc, L.ACT[act], layers, 1.2, 0.3, 0.9, k0.ptr, n, n, ld, q.ptr, q.ptr,
-               1, L.GET_NNGP, k1.ptr, None, ld)
+               sym, L.GET_NNGP, k1.ptr, None, ld)
         k1h = k1.numpy()[:, :n]
         assert relerr(k1h, rk) < RTOL[dtype]
-        if sym == "1":
+        if sym == 1:
             assert (got[sym][0] == got[sym][0].T).all() and (got[sym][1] == got[sym][1].T).all()
             assert (k1h == k1h.T).all()
-    il = np.tril_indices(n)
-    assert relerr(got["1"][0][il], got["0"][0][il]) < (1e-6 if dtype == np.float32 else 1e-14)
+    il = np.tril_indices(n, -1)        # (the cross form has no closed-form diagonal)
+    assert relerr(got[1][0][il], got[0][0][il]) < (1e-6 if dtype == np.float32 else 1e-14)
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
@@ -375,12 +370,10 @@ def test_cnn_kernel(dtype, act, shape, layers):
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("act", ["relu", "erf"])
-def test_cnn_kernel_32x32_stencil_in_registers_matches_the_lds_map_kernel(L, dtype, act):
-    """32 x 32 images take conv_pair32_kernel (3x3 box sums by DPP lane shifts + v_permlane32_swap, no LDS); the generic
-    LDS-map kernel (SMN_CNN_FAST32=0) must give the same kernel: same sums in a different association order, so to a
-    few ulp, and both against the oracle.  Images with structure at the borders (a constant image makes every border
-    and corner pixel a distinct case)."""
-    import os
+def test_cnn_kernel_32x32_forms_agree_at_the_image_borders(L, ctx, dtype, act):
+    """32 x 32 x 3 images: fp64 takes the 4x4-patch kernel (stencil in registers, halo by ds_bpermute), fp32 the LDS-map
+    kernel; both against the oracle and against each other to fp32 accuracy.  Images with structure at the borders (a
+    constant image makes every border and corner pixel a distinct case)."""
     rng = np.random.default_rng(11)
     n = 6
     x = rng.standard_normal((n, 32, 32, 3))
@@ -388,62 +381,34 @@ def test_cnn_kernel_32x32_stencil_in_registers_matches_the_lds_map_kernel(L, dty
     x[1, 0, :, :] = 5.0             # loud top row
     x[2, :, 31, :] = -4.0           # loud right column
     x[3, 31, 0, :] = 7.0            # loud corner
-    x = x.astype(dtype)
 
-    def run(env):
-        old = os.environ.get("SMN_CNN_FAST32")
-        os.environ["SMN_CNN_FAST32"] = env
-        try:
-            c = L.Context(0)
-        finally:
-            if old is None:
-                del os.environ["SMN_CNN_FAST32"]
-            else:
-                os.environ["SMN_CNN_FAST32"] = old
-        xd = c.to_device(x)
-        k = c.empty((n, n), dtype)
-        c.call("smn_kernel_cnn", L.dtype_code(dtype), L.ACT[act], 4, 1.2, 0.3, 0.9, xd.ptr, n, None, 0, 32, 32, 3, L.FILL_FULL, k.ptr, n)
+    def run(dt):
+        xd = ctx.to_device(x.astype(dt))
+        k = ctx.empty((n, n), dt)
+        ctx.call("smn_kernel_cnn", L.dtype_code(dt), L.ACT[act], 4, 1.2, 0.3, 0.9, xd.ptr, n, None, 0, 32, 32, 3, L.FILL_FULL, k.ptr, n)
         return k.numpy()
 
-    fast, slow = run("2"), run("0")      # 2: the register form in both precisions
-    ref = O.cnn_kernel(x.astype(np.float64), None, 4, act, 1.2, 0.3, 0.9)
-    tol = 1e-12 if dtype == np.float64 else 2e-5
-    assert np.abs(fast - slow).max() < tol * np.abs(ref).max()
-    assert relerr(fast, ref) < RTOL[dtype] and relerr(slow, ref) < RTOL[dtype]
+    got = run(dtype)
+    ref = O.cnn_kernel(x.astype(dtype).astype(np.float64), None, 4, act, 1.2, 0.3, 0.9)
+    assert relerr(got, ref) < RTOL[dtype]
+    other = run(np.float32 if dtype == np.float64 else np.float64)
+    assert np.abs(got - other).max() < 2e-5 * np.abs(ref).max()
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
-def test_cnn_kernel_tiled_pair_order(L, dtype):
-    """Large pair counts take the XCD-tiled pair order (cnn.hip): symmetric (ragged last tiles, half-empty diagonal
-    tiles) and cross kernels against the oracle, and bit for bit against the plain order (SMN_CNN_TILED=0)."""
-    import os
+def test_cnn_kernel_tiled_pair_order(L, ctx, dtype):
+    """Large pair counts take the XCD-tiled pair order (cnn.hip: from 4 tiles of pairs per XCD-resident workgroup on):
+    symmetric (ragged last tiles, half-empty diagonal tiles) and cross kernels against the oracle."""
     rng = np.random.default_rng(3)
-    n1, n2, shape = 421, 333, (6, 6, 1)
+    n1, n2, shape = 1531, 1203, (6, 6, 1)
     x = rng.standard_normal((n1,) + shape).astype(dtype)
     x2 = rng.standard_normal((n2,) + shape).astype(dtype)
-
-    def run(env):
-        old = os.environ.get("SMN_CNN_TILED")
-        if env is not None:
-            os.environ["SMN_CNN_TILED"] = env
-        try:
-            c = L.Context(0)
-        finally:
-            if env is not None:
-                if old is None:
-                    del os.environ["SMN_CNN_TILED"]
-                else:
-                    os.environ["SMN_CNN_TILED"] = old
-        xd, x2d = c.to_device(x), c.to_device(x2)
-        ks, kc = c.empty((n1, n1), dtype), c.empty((n1, n2), dtype)
-        code = L.dtype_code(dtype)
-        c.call("smn_kernel_cnn", code, L.ACT["relu"], 2, 1.3, 0.2, 0.9, xd.ptr, n1, None, 0, 6, 6, 1, L.FILL_FULL, ks.ptr, n1)
-        c.call("smn_kernel_cnn", code, L.ACT["relu"], 2, 1.3, 0.2, 0.9, xd.ptr, n1, x2d.ptr, n2, 6, 6, 1, L.FILL_FULL, kc.ptr, n2)
-        return ks.numpy(), kc.numpy()
-
-    ks, kc = run("2")      # tiled at any size
-    ks0, kc0 = run("0")
-    assert np.array_equal(ks, ks0) and np.array_equal(kc, kc0)
+    xd, x2d = ctx.to_device(x), ctx.to_device(x2)
+    ksd, kcd = ctx.empty((n1, n1), dtype), ctx.empty((n1, n2), dtype)
+    code = L.dtype_code(dtype)
+    ctx.call("smn_kernel_cnn", code, L.ACT["relu"], 2, 1.3, 0.2, 0.9, xd.ptr, n1, None, 0, 6, 6, 1, L.FILL_FULL, ksd.ptr, n1)
+    ctx.call("smn_kernel_cnn", code, L.ACT["relu"], 2, 1.3, 0.2, 0.9, xd.ptr, n1, x2d.ptr, n2, 6, 6, 1, L.FILL_FULL, kcd.ptr, n2)
+    ks, kc = ksd.numpy(), kcd.numpy()
     assert np.array_equal(ks, ks.T)
     ref = O.cnn_kernel(x.astype(np.float64), None, 2, "relu", 1.3, 0.2, 0.9)
     refc = O.cnn_kernel(x.astype(np.float64), x2.astype(np.float64), 2, "relu", 1.3, 0.2, 0.9)
@@ -623,12 +588,9 @@ def test_cholesky_more_workgroups_than_cus_and_lookahead(L, ctx, dtype, n, m):
     {"SMN_SUPER": "512"},
     {"SMN_SUPER": "2048"},
     {"SMN_SUPER": "512", "SMN_CHAIN_CUS": "0"},
-    {"SMN_PERSISTENT": "0"},
     {"SMN_XCD_MAP": "0"},                                      # linear tile order instead of the XCD patch order
     {"SMN_SUPER_WIDE_ROWS": "4096"},                           # 2048-column super-panels while 4096 rows are left, 1024 below
-    {"SMN_SUPER_WIDE_ROWS": "0", "SMN_SUPER_WIDE": "3072"},    # 3072-column super-panels throughout
-    {"SMN_F0_FIRST_TILES": "0"},                               # F1 always beside F0
-    {"SMN_F0_FIRST_TILES": "100000"},                          # F1 always behind F0
+    {"SMN_SUPER_WIDE_ROWS": "0"},                              # 2048-column super-panels throughout
     {"SMN_PANEL_LEAF": "0"},                                   # the in-LDS micro-panel kernel (panel_kernel) instead of the register leaf
 ])
 def test_cholesky_schedule_variants_agree(L, env):
@@ -1272,124 +1234,153 @@ def test_too_many_output_columns_is_rejected_before_anything_runs(L, ctx):
     assert e.value.code == L.ENOTSUP
 
 
-# ----------------------------------------------------------------------------- pipelined exchange (pieces of the chunks)
-@pytest.mark.parametrize("n,d,world,parts", [(1000, 24, 3, 4), (2048, 16, 2, 8), (700, 10, 1, 2), (1536, 8, 4, 1)])
-def test_pipelined_pieces_assemble_the_same_kernel(L, ctx, n, d, world, parts):
-    """`world` ranks played on one GPU: each builds its chunk piece by piece (smn_kernel_mlp_shard_rows over
-    sharding.part_tile_rows), the pieces are laid out as the part-wise all-gather leaves them ([part][rank][piece]) and
-    scattered with smn_unpack_lower_parts: the lower triangle equals the one-launch kernel bit for bit, and everything
-    the scatter does not own stays untouched (NaN-poisoned target and staging)."""
+# ----------------------------------------------------------------------------- column-first exchange (cyclic layout)
+from _played import play_ranks as _play_ranks  # noqa: E402  (tests/_played.py: P ranks played on one GPU)
+
+
+@pytest.mark.parametrize("n,d,world,cols,dtype", [(1000, 24, 3, [0, 3, 6, 8], np.float32), (2048, 16, 2, None, np.float32),
+                                                    (700, 10, 1, [0, 2, 6], np.float32), (1536, 8, 4, [0, 12], np.float32),
+                                                    (1100, 12, 8, [0, 8, 9], np.float64), (3000, 8, 5, None, np.float32)])
+def test_column_first_pieces_assemble_the_same_kernel(L, ctx, n, d, world, cols, dtype):
+    """`world` ranks played on one GPU in the cyclic column-first layout: the scattered pieces (smn_shard_scatter_cols into a
+    matrix of the caller's) equal the one-launch kernel bit for bit on the lower triangle by 128-column tiles, NNGP and
+    NTK, and everything the scatter does not own stays untouched (NaN-poisoned target and staging)."""
     from smnngp import sharding as S
     rng = np.random.default_rng(90 + n)
-    xh = rng.standard_normal((n, d)).astype(np.float32)
-    x = ctx.to_device(xh)
+    x = ctx.to_device(rng.standard_normal((n, d)).astype(dtype))
+    code = L.dtype_code(dtype)
     spec = (L.NET_MLP, L.ACT["relu"], 2, 1.3, 0.2, 1.0)
-    h, chunk = S.block_rows(n, world), S.paired_chunk_elems(n, world)
-    piece = chunk // parts
-    stage = ctx.to_device(np.full(world * chunk, np.nan, np.float32))
-    stage_t = ctx.to_device(np.full(world * chunk, np.nan, np.float32))      # the NTK rides the same pieces (config 5)
-    be = S.DeviceBackend(ctx)
-    for r in range(world):
-        mine = ctx.to_device(np.full(chunk, np.nan, np.float32))
-        mine_t = ctx.to_device(np.full(chunk, np.nan, np.float32))
-        padded = False
-        for g, rows in enumerate(S.part_tile_rows(n, world, r, parts)):
-            if rows[1] > rows[0] or rows[3] > rows[2]:
-                be.build_rows(L.F32, spec, x.ptr, n, d, d, world, r, h, rows, padded, mine.ptr, mine_t.ptr)
-                padded = True
-            # what the all-gather of piece g does for rank r
-            for src, dst in ((mine, stage), (mine_t, stage_t)):
-                ctx.call("smn_memcpy_d2d", C.c_void_p(dst.ptr.value + 4 * (g * world + r) * piece),
-                         C.c_void_p(src.ptr.value + 4 * g * piece), 4 * piece)
-        ctx.synchronize()
-        del mine, mine_t
-    k = ctx.to_device(np.full((n, n), np.nan, np.float32))
-    kt = ctx.to_device(np.full((n, n), np.nan, np.float32))
-    ctx.call("smn_unpack_lower_parts", L.F32, stage.ptr, n, world, h, parts, 0, parts, k.ptr, n)
-    ctx.call("smn_unpack_lower_parts", L.F32, stage_t.ptr, n, world, h, parts, 0, parts, kt.ptr, n)
-    ref = ctx.empty((n, n), np.float32)
-    ref_t = ctx.empty((n, n), np.float32)
-    ctx.call("smn_kernel_mlp", L.F32, *spec, x.ptr, n, d, None, 0, 0, d, L.GET_NNGP | L.GET_NTK, L.FILL_LOWER, ref.ptr, ref_t.ptr, n)
+    cols = cols or S.default_col_pieces(n, world)
+    stage, stage_t = _play_ranks(L, ctx, spec, x, n, d, world, cols, dtype)
+    k = ctx.to_device(np.full((n, n), np.nan, dtype))
+    kt = ctx.to_device(np.full((n, n), np.nan, dtype))
+    ca = S.cols_array(cols)
+    for g in reversed(range(len(cols) - 1)):                  # any order: the pieces are disjoint
+        ctx.call("smn_shard_scatter_cols", code, stage.ptr, n, world, len(cols) - 1, ca, g, k.ptr, n)
+        ctx.call("smn_shard_scatter_cols", code, stage_t.ptr, n, world, len(cols) - 1, ca, g, kt.ptr, n)
+    ctx.call("smn_shard_wait")
+    ref = ctx.empty((n, n), dtype)
+    ref_t = ctx.empty((n, n), dtype)
+    ctx.call("smn_kernel_mlp", code, *spec, x.ptr, n, d, None, 0, 0, d, L.GET_NNGP | L.GET_NTK, L.FILL_LOWER, ref.ptr, ref_t.ptr, n)
     rr, cc = np.indices((n, n))
     own = cc < np.minimum(n, (rr // 128 + 1) * 128)          # the lower triangle by 128-column tiles
     for got, want in ((k.numpy(), ref.numpy()), (kt.numpy(), ref_t.numpy())):
         assert np.array_equal(got[own], want[own])
         assert np.isnan(got[~own]).all()
+    if world > 1:
+        with pytest.raises(L.SmnError):                       # boundaries that are not multiples of the world
+            ctx.call("smn_shard_scatter_cols", code, stage.ptr, n, world, 2, S.cols_array([0, 1, S.tile_rows(n)]), 0, k.ptr, n)
 
 
-def test_pipelined_route_on_a_one_rank_communicator(L, ctx):
-    """smn_shard_begin -> build rows -> smn_shard_exchange_part (RCCL, one rank, on the communication stream) ->
-    smn_lml_from_shards equals the fused smn_spr_loss; a world the communicator does not have is refused."""
+@pytest.mark.parametrize("world,order,delay", [(2, "forward", None), (4, "reverse", (2, 20000)), (8, "forward", (2, 30000)),
+                                                (8, "odd-first", (1, 10000)), (3, "reverse", None)])
+def test_column_first_lml_is_bit_identical_whatever_the_arrival_order(L, world, order, delay):
+    """P ranks played on one GPU, pieces scattered into the factorisation workspace in a forced order and behind a held
+    stream (smn_debug_delay), with the look-ahead schedule on (SMN_CHAIN_MIN_N lowered): the factorisation waits for each
+    piece where it first touches its columns and the log-pdf, quadratic form and logdet equal the fused single-GPU
+    smn_spr_loss bit for bit."""
+    import os
+    from smnngp import sharding as S
+    old = os.environ.get("SMN_CHAIN_MIN_N")
+    os.environ["SMN_CHAIN_MIN_N"] = "1024"
+    try:
+        c2 = L.Context(0)
+    finally:
+        if old is None:
+            del os.environ["SMN_CHAIN_MIN_N"]
+        else:
+            os.environ["SMN_CHAIN_MIN_N"] = old
+    n, d, eps = 4000, 16, 1e-2
+    rng = np.random.default_rng(17)
+    x = c2.to_device(rng.standard_normal((n, d)).astype(np.float32)); y = c2.to_device(rng.standard_normal(n).astype(np.float32))
+    spec = (L.NET_MLP, L.ACT["relu"], 3, 1.2, 0.25, 1.0)
+    lp, quad, logdet, info = C.c_double(), C.c_double(), C.c_double(), C.c_int()
+    c2.call("smn_spr_loss", L.F32, *spec, x.ptr, n, d, d, y.ptr, eps, 4.0, 1.5, C.byref(lp), C.byref(quad), C.byref(logdet), C.byref(info))
+    want = (lp.value, quad.value, logdet.value, info.value)
+    assert want[3] == 0
+    cols = S.default_col_pieces(n, world)
+    assert len(cols) - 1 >= 3
+    stage, _ = _play_ranks(L, c2, spec, x, n, d, world, cols, with_ntk=False)
+    ca = S.cols_array(cols)
+    pieces = list(range(len(cols) - 1))
+    if order == "reverse":
+        pieces.reverse()
+    elif order == "odd-first":
+        pieces = pieces[1::2] + pieces[0::2]
+    for rep in range(2):                                       # twice: the events of the pieces are reused
+        c2.call("smn_shard_begin", L.F32, n, eps)
+        for i, g in enumerate(pieces):
+            if delay is not None and i in (0, len(pieces) - 1):
+                c2.call("smn_debug_delay", delay[0], delay[1])
+            c2.call("smn_shard_scatter_cols", L.F32, stage.ptr, n, world, len(cols) - 1, ca, g, None, 0)
+        c2.call("smn_lml_from_shards", L.F32, n, y.ptr, 4.0, 1.5, C.byref(lp), C.byref(quad), C.byref(logdet), C.byref(info))
+        assert (lp.value, quad.value, logdet.value, info.value) == want
+    # a column range that never went out is refused, not factored
+    c2.call("smn_shard_begin", L.F32, n, eps)
+    for g in pieces[1:]:
+        c2.call("smn_shard_scatter_cols", L.F32, stage.ptr, n, world, len(cols) - 1, ca, g, None, 0)
+    with pytest.raises(L.SmnError):
+        c2.call("smn_lml_from_shards", L.F32, n, y.ptr, 0.0, 1.0, C.byref(lp), C.byref(quad), C.byref(logdet), C.byref(info))
+    c2.call("smn_shard_begin", L.F32, n, eps)                  # the abandoned pipeline is joined and forgotten
+    c2.synchronize()
+    del x, y, stage
+    c2.close()
+
+
+def test_column_first_route_on_a_one_rank_communicator(L, ctx):
+    """smn_shard_begin -> one build -> smn_shard_exchange_cols per piece (RCCL, one rank, communication + scatter streams)
+    -> smn_lml_from_shards equals the fused smn_spr_loss bit for bit; a world the communicator does not have is refused."""
     from smnngp import sharding as S
     n, d = 1500, 20
     rng = np.random.default_rng(91)
     x = ctx.to_device(rng.standard_normal((n, d)).astype(np.float32)); y = ctx.to_device(rng.standard_normal(n).astype(np.float32))
     spec = (L.NET_MLP, L.ACT["erf"], 3, 1.4, 0.3, 0.9)
+    lp, quad, logdet, info = C.c_double(), C.c_double(), C.c_double(), C.c_int()
+    ctx.call("smn_spr_loss", L.F32, *spec, x.ptr, n, d, d, y.ptr, 1e-2, 0.0, 1.0, C.byref(lp), C.byref(quad),
+             C.byref(logdet), C.byref(info))
+    assert info.value == 0
     c2 = L.Context(ctx.device)
     uid = C.create_string_buffer(128)
     assert L._lib.smn_comm_unique_id(uid) == 0
     c2.call("smn_comm_init", 1, 0, uid)
     x2 = c2.to_device(x.numpy()); y2 = c2.to_device(y.numpy())
-    chunk = S.paired_chunk_elems(n, 1)
-    mine = c2.empty((chunk,), np.float32); stage = c2.empty((chunk,), np.float32)
-    for parts in (1, 2, 4):
-        got = S.lml_sharded_pipelined(S.DeviceBackend(c2), L.F32, spec, x2.ptr, n, d, d, y2.ptr, 0, 1, mine.ptr, stage.ptr,
-                                      1e-2, parts=parts)
-        lp, quad, logdet, info = C.c_double(), C.c_double(), C.c_double(), C.c_int()
-        ctx.call("smn_spr_loss", L.F32, *spec, x.ptr, n, d, d, y.ptr, 1e-2, 0.0, 1.0, C.byref(lp), C.byref(quad),
-                 C.byref(logdet), C.byref(info))
-        assert got[3] == 0 and info.value == 0
-        assert abs(got[0] - lp.value) < 1e-6 * abs(lp.value) and abs(got[2] - logdet.value) < 1e-6 * abs(logdet.value)
+    t_all = S.tile_rows(n)
+    for cols in ([0, t_all], [0, 4, t_all], list(range(0, t_all, 2)) + [t_all]):
+        elems = S.col_layout(n, 1, cols)["elems"]
+        mine = c2.empty((elems,), np.float32); stage = c2.empty((elems,), np.float32)
+        phases = []
+        got = S.lml_sharded_cols(S.DeviceBackend(c2), L.F32, spec, x2.ptr, n, d, d, y2.ptr, 0, 1, mine.ptr, stage.ptr,
+                                 1e-2, cols=cols, progress=phases.append)
+        assert got[3] == 0 and got[0] == lp.value and got[2] == logdet.value and got[1] == quad.value
+        assert phases[0] == "begin" and phases[-1] == "factor"
+        del mine, stage
+    cols = [0, 4, 8, t_all]
+    elems = S.col_layout(n, 1, cols)["elems"]
+    mine = c2.empty((elems,), np.float32); stage = c2.empty((elems,), np.float32)
     with pytest.raises(RuntimeError):
-        S.lml_sharded_pipelined(S.DeviceBackend(c2), L.F32, spec, x2.ptr, n, d, d, y2.ptr, 0, 2, mine.ptr, stage.ptr, 1e-2)
-    # BASELINE config 5: NNGP + NTK through the same pipeline (smn_shard_exchange_part_to), with the sharded build on the
-    # CU-masked stream that keeps CUs free for RCCL's kernels (forced here: a one-rank communicator would not ask for it)
-    import os
-    os.environ["SMN_COMM_CUS_FORCE"] = "1"
-    try:
-        c3 = L.Context(ctx.device)
-    finally:
-        del os.environ["SMN_COMM_CUS_FORCE"]
-    assert L._lib.smn_comm_unique_id(uid) == 0
-    c3.call("smn_comm_init", 1, 0, uid)
-    x3 = c3.to_device(x.numpy()); y3 = c3.to_device(y.numpy())
-    mine3 = c3.empty((chunk,), np.float32); stage3 = c3.empty((chunk,), np.float32)
-    mine_t = c3.empty((chunk,), np.float32); stage_t = c3.empty((chunk,), np.float32)
-    tk = c3.to_device(np.full((n, n), np.nan, np.float32))
-    got = S.lml_sharded_pipelined(S.DeviceBackend(c3), L.F32, spec, x3.ptr, n, d, d, y3.ptr, 0, 1, mine3.ptr, stage3.ptr,
-                                  1e-2, parts=4, ntk=(mine_t.ptr, stage_t.ptr, tk.ptr, n))
-    assert got[3] == 0 and abs(got[0] - lp.value) < 1e-6 * abs(lp.value)
+        S.lml_sharded_cols(S.DeviceBackend(c2), L.F32, spec, x2.ptr, n, d, d, y2.ptr, 0, 2, mine.ptr, stage.ptr, 1e-2)
+    # BASELINE config 5: NNGP + NTK through the same exchange (smn_shard_exchange_cols_to)
+    mine_t = c2.empty((elems,), np.float32); stage_t = c2.empty((elems,), np.float32)
+    tk = c2.to_device(np.full((n, n), np.nan, np.float32))
+    got = S.lml_sharded_cols(S.DeviceBackend(c2), L.F32, spec, x2.ptr, n, d, d, y2.ptr, 0, 1, mine.ptr, stage.ptr,
+                             1e-2, cols=cols, ntk=(mine_t.ptr, stage_t.ptr, tk.ptr, n))
+    assert got[3] == 0 and got[0] == lp.value
     ref = ctx.empty((n, n), np.float32); ref_t = ctx.empty((n, n), np.float32)
     ctx.call("smn_kernel_mlp", L.F32, *spec, x.ptr, n, d, None, 0, 0, d, L.GET_NNGP | L.GET_NTK, L.FILL_LOWER, ref.ptr, ref_t.ptr, n)
     rr, cc = np.indices((n, n))
     own = cc < np.minimum(n, (rr // 128 + 1) * 128)
     assert np.array_equal(tk.numpy()[own], ref_t.numpy()[own]) and np.isnan(tk.numpy()[~own]).all()
-    with pytest.raises(L.SmnError):
-        c3.call("smn_shard_exchange_part_to", L.F32, mine_t.ptr, stage_t.ptr, n, 2, S.block_rows(n, 1), 4, 0, tk.ptr, n)
-    c3.call("smn_comm_destroy")
-    with pytest.raises(RuntimeError):       # the unpipelined route checks the communicator too
+    ca = S.cols_array(cols)
+    with pytest.raises(L.SmnError) as e:                      # a world the communicator does not have
+        c2.call("smn_shard_exchange_cols_to", L.F32, mine_t.ptr, stage_t.ptr, n, 2, len(cols) - 1, S.cols_array([0, 4, 8, t_all]), 0, tk.ptr, n)
+    assert e.value.code == L.ECOMM
+    with pytest.raises(L.SmnError):                           # the exchange without smn_shard_begin
+        c2.call("smn_shard_exchange_cols", L.F32, mine.ptr, stage.ptr, n, 1, len(cols) - 1, ca, 0)
+    with pytest.raises(RuntimeError):       # the monolithic paired route checks the communicator too
         S.build_lower_sharded(c2, L.F32, 4, *spec, x2.ptr, n, d, d, 0, 2, stage.ptr, None, 0)
     c2.call("smn_comm_destroy")
-    del x2, y2, mine, stage
-    c2.close()
-
-
-def test_allgather_part_and_comm_info(L, ctx):
-    """smn_allgather_part moves piece g of the chunk to stage[g][rank][piece]; without a communicator (and with a one-rank
-    one) that is a copy; smn_comm_info reports the communicator's size."""
     nr, rk = C.c_int(-1), C.c_int(-1)
-    ctx.call("smn_comm_info", C.byref(nr), C.byref(rk))
+    c2.call("smn_comm_info", C.byref(nr), C.byref(rk))
     assert (nr.value, rk.value) == (1, 0)
-    chunk, parts = 4096, 4
-    piece = chunk // parts
-    src = np.arange(chunk, dtype=np.float32)
-    mine = ctx.to_device(src); stage = ctx.to_device(np.full(chunk, np.nan, np.float32))
-    for g in (2, 0):
-        ctx.call("smn_allgather_part", L.F32, mine.ptr, stage.ptr, chunk, parts, g)
-    got = stage.numpy()
-    assert np.array_equal(got[2 * piece: 3 * piece], src[2 * piece: 3 * piece]) and np.array_equal(got[:piece], src[:piece])
-    assert np.isnan(got[piece: 2 * piece]).all() and np.isnan(got[3 * piece:]).all()
-    with pytest.raises(L.SmnError):
-        ctx.call("smn_allgather_part", L.F32, mine.ptr, stage.ptr, chunk, parts, parts)
-    with pytest.raises(L.SmnError):     # the pipelined exchange without smn_shard_begin
-        ctx.call("smn_shard_exchange_part", L.F32, mine.ptr, stage.ptr, 999, 1, 128, 1, 0)
+    del x2, y2, mine, stage, mine_t, stage_t, tk
+    c2.close()

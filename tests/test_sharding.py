@@ -188,34 +188,52 @@ def test_world_size_2_gloo_paired_lower_blocks(n):
     assert abs(lml - ref_lml) < 1e-9 * abs(ref_lml)
 
 
-# ------------------------------------------------------------------ pipelined exchange: the real driver, a CPU backend
-def test_part_tile_rows_build_every_tile_row_once_before_its_piece_is_gathered():
+# ------------------------------------------------------------------ cyclic column-first exchange: the real driver, a CPU backend
+def test_cyclic_layout_is_balanced_and_every_column_range_is_an_equal_count_gather():
     from smnngp import sharding as S
-    for n, w in [(16384, 8), (16384, 2), (32768, 8), (4096, 4), (301, 2), (1000, 3), (128, 8)]:
-        h, chunk, tpb = S.block_rows(n, w), S.paired_chunk_elems(n, w), S.block_rows(n, w) // S.TILE
-        for parts in {1, 2, S.default_parts(n, w)}:
-            piece = chunk // parts
+    for n, w in [(16384, 8), (16384, 2), (32768, 8), (4096, 4), (301, 2), (1000, 3), (128, 8), (20000, 8), (5000, 5)]:
+        t_all = S.tile_rows(n)
+        owned = sorted(t for r in range(w) for t in S.rank_tile_rows(n, w, r))
+        assert owned == list(range(t_all))                                      # every tile row exactly once
+        for t in range(t_all):
+            assert t in S.rank_tile_rows(n, w, S.tile_row_owner(w, t))
+        tiles = [sum(t + 1 for t in S.rank_tile_rows(n, w, r)) for r in range(w)]
+        if t_all % (2 * w) == 0:
+            assert len(set(tiles)) == 1                                         # exactly balanced over whole periods
+        else:
+            assert max(tiles) - min(tiles) <= 2 * t_all                         # at most ~one period's worth apart
+        cols = S.default_col_pieces(n, w)
+        lay = S.col_layout(n, w, cols)
+        assert cols[0] == 0 and cols[-1] == t_all and len(cols) - 1 <= 16
+        assert all(c % w == 0 for c in cols[:-1])
+        seen = set()
+        for g in range(len(cols) - 1):
             for r in range(w):
-                lo, hi = S.paired_blocks(w, r)
-                ld = [(lo + 1) * h, (hi + 1) * h]
-                built = [0, 0]
-                for g, rows in enumerate(S.part_tile_rows(n, w, r, parts)):
-                    assert rows[0] == built[0] and rows[2] == built[1] and rows[1] >= rows[0] and rows[3] >= rows[2]
-                    built = [rows[1], rows[3]]
-                    # every element of pieces <= g lies in a tile row built by now
-                    done = built[0] * S.TILE * ld[0] if built[0] < tpb else h * ld[0] + built[1] * S.TILE * ld[1]
-                    assert done >= min(chunk, (g + 1) * piece)
-                assert built == [tpb, tpb]
-    assert S.default_parts(16384, 8) == 4 and S.default_parts(32768, 8) == 8 and S.default_parts(16384, 1) == 8
-    assert S.default_parts(16384, 2) == 16 and S.default_parts(16384, 4) == 8 and S.default_parts(4096, 2) in (1, 2)
+                # the rank's tile rows from the piece's first column down fit the piece's slots, in order
+                mine = [t for t in S.rank_tile_rows(n, w, r) if t >= cols[g]]
+                assert len(mine) <= lay["slots"][g]
+                for i, t in enumerate(mine):
+                    assert t == S.rank_tile_row(w, r, cols[g] // w + i)
+                    for tc in range(cols[g], min(cols[g + 1], t + 1)):
+                        assert (t, tc) not in seen
+                        seen.add((t, tc))
+            assert lay["count"][g] == lay["slots"][g] * S.TILE * lay["width"][g]
+        assert len(seen) == t_all * (t_all + 1) // 2                             # every lower tile in exactly one piece
+        assert lay["elems"] == sum(lay["count"])
+    assert S.default_col_pieces(16384, 8) == list(range(0, 129, 8))
+    assert S.default_col_pieces(32768, 8) == list(range(0, 257, 16))
+    lay = S.col_layout(16384, 8, S.default_col_pieces(16384, 8))
+    assert lay["elems"] * 8 < 1.06 * 128 * 129 // 2 * 128 * 128                  # 5.4 % above-diagonal padding
     with pytest.raises(ValueError):
-        S.part_tile_rows(1000, 3, 0, 5)
+        S.col_layout(1000, 3, [0, 4, 8])             # boundaries must be multiples of the world
+    with pytest.raises(ValueError):
+        S.col_layout(1000, 2, [0, 4])                # ... and span every tile column
 
 
 class _CpuBackend:
-    """The device steps of sharding.lml_sharded_pipelined restated on the host: oracle rows for the build, a gloo
-    all-gather per piece, NumPy for the scatter (the mapping of csrc/comm.hip unpack_part_kernel) and the head.  `mine` and
-    `stage` are NumPy arrays handed through the driver untouched."""
+    """The device steps of sharding.lml_sharded_cols restated on the host: oracle rows for the build, a gloo all-gather
+    per piece, NumPy for the scatter (the mapping of csrc/comm.hip scatter_piece_kernel, jitter on the diagonal included)
+    and the head.  `mine` and `stage` are NumPy arrays handed through the driver untouched."""
 
     def __init__(self, dist, torch, x, y, world, rank):
         self.dist, self.torch, self.x, self.y, self.world, self.rank = dist, torch, x, y, world, rank
@@ -224,67 +242,76 @@ class _CpuBackend:
     def comm_size(self):
         return self.dist.get_world_size()
 
-    def begin(self, dtype_code, n):
+    def begin(self, dtype_code, n, eps_abs):
         self.k = np.full((n, n), np.nan)
+        self.eps = eps_abs
         self.calls.append("begin")
 
-    def build_rows(self, dtype_code, spec, x_ptr, n, ldx, d, world, rank, h, rows, reuse, mine, ntk_mine=None):
+    def build_cols(self, dtype_code, spec, x_ptr, n, ldx, d, world, rank, cols, mine, ntk_mine=None):
         from oracle import nngp_oracle as O
         from smnngp import sharding as S
         _net, act, nh, w_std, b_std, lw = spec
-        lo, hi = S.paired_blocks(world, rank)
-        for blk, t0, t1, base in ((lo, rows[0], rows[1], 0), (hi, rows[2], rows[3], h * (lo + 1) * h)):
-            rb, re = min(n, blk * h + t0 * S.TILE), min(n, blk * h + t1 * S.TILE)
-            if re <= rb:
-                continue
-            ld = (blk + 1) * h
-            kr = O.mlp_kernel(self.x[rb:re], self.x[:re], nh, "relu" if act == 0 else "erf", w_std, b_std, lw)
-            kr[np.arange(re - rb), np.arange(rb, re)] = O.diag_recursion((self.x[rb:re] ** 2).sum(1) / d, nh,
-                                                                         "relu" if act == 0 else "erf", w_std, b_std, lw)
-            if ntk_mine is not None:
-                both = O.mlp_kernel(self.x[rb:re], self.x[:re], nh, "relu" if act == 0 else "erf", w_std, b_std, lw, get=("nngp", "ntk"))
-                kt = both[1]
-                if re - rb:                                   # exact diagonal, as the device kernel writes it
-                    full = O.mlp_kernel(self.x[rb:re], None, nh, "relu" if act == 0 else "erf", w_std, b_std, lw, get=("nngp", "ntk"))[1]
-                    kt[np.arange(re - rb), np.arange(rb, re)] = np.diag(full)
-            for i in range(re - rb):
-                o = base + (rb - blk * h + i) * ld
-                mine[o: o + re] = kr[i]
-                if ntk_mine is not None:
-                    ntk_mine[o: o + re] = kt[i]
-        self.calls.append(("build", rows, bool(reuse)))
+        act = "relu" if act == 0 else "erf"
+        lay = S.col_layout(n, world, cols)
+        for t in S.rank_tile_rows(n, world, rank):
+            rb, re = t * S.TILE, min(n, (t + 1) * S.TILE)
+            both = O.mlp_kernel(self.x[rb:re], self.x[:re], nh, act, w_std, b_std, lw, get=("nngp", "ntk"))
+            full = O.mlp_kernel(self.x[rb:re], None, nh, act, w_std, b_std, lw, get=("nngp", "ntk"))
+            kr, kt = both[0], both[1]
+            kr[np.arange(re - rb), np.arange(rb, re)] = np.diag(full[0])        # exact diagonal, as the device kernel writes it
+            kt[np.arange(re - rb), np.arange(rb, re)] = np.diag(full[1])
+            for g in range(len(cols) - 1):
+                if cols[g] > t:
+                    break
+                slot = (t - cols[g]) // world
+                assert S.rank_tile_row(world, rank, cols[g] // world + slot) == t
+                c0, c1 = cols[g] * S.TILE, min(re, cols[g + 1] * S.TILE)
+                wd = lay["width"][g]
+                for i in range(re - rb):
+                    o = lay["off"][g] + (slot * S.TILE + i) * wd
+                    mine[o: o + c1 - c0] = kr[i, c0:c1]
+                    if ntk_mine is not None:
+                        ntk_mine[o: o + c1 - c0] = kt[i, c0:c1]
+        self.calls.append(("build", tuple(cols)))
 
-    def exchange_part(self, dtype_code, mine, stage, n, world, h, parts, part, ntk=None):
+    def exchange_cols(self, dtype_code, mine, stage, n, world, cols, piece, ntk=None):
         if ntk is not None:                                   # the same piece of the NTK chunks into the caller's matrix
-            self._exchange(ntk[0], ntk[1], n, world, h, parts, part, ntk[2])
-        self._exchange(mine, stage, n, world, h, parts, part, self.k)
-        self.calls.append(("exchange", part))
+            self._exchange(ntk[0], ntk[1], n, world, cols, piece, ntk[2], 0.0)
+        self._exchange(mine, stage, n, world, cols, piece, self.k, self.eps)
+        self.calls.append(("exchange", piece))
 
-    def _exchange(self, mine, stage, n, world, h, parts, part, out):
-        piece = mine.size // parts
-        recv = self.torch.from_numpy(stage[part * world * piece: (part + 1) * world * piece])
-        self.dist.all_gather_into_tensor(recv, self.torch.from_numpy(mine[part * piece: (part + 1) * piece].copy()))
-        for r in range(world):                                   # unpack_part_kernel, element by element
-            low = h * (r + 1) * h
-            for v in range(piece):
-                e = part * piece + v
-                if e < low:
-                    b, ld, ee = r, (r + 1) * h, e
-                else:
-                    b, ld, ee = 2 * world - 1 - r, (2 * world - r) * h, e - low
-                row, col = b * h + ee // ld, ee % ld
-                if row < n and col < min(n, (row // 128 + 1) * 128):
-                    out[row, col] = stage[(part * world + r) * piece + v]
+    def _exchange(self, mine, stage, n, world, cols, g, out, diag_add):
+        from smnngp import sharding as S
+        lay = S.col_layout(n, world, cols)
+        cnt, off, wd = lay["count"][g], lay["off"][g], lay["width"][g]
+        recv = self.torch.from_numpy(stage[world * off: world * (off + cnt)])
+        self.dist.all_gather_into_tensor(recv, self.torch.from_numpy(mine[off: off + cnt].copy()))
+        t_all = S.tile_rows(n)
+        for r in range(world):                                   # scatter_piece_kernel, strip row by strip row
+            for srow in range(lay["slots"][g] * S.TILE):
+                j = cols[g] // world + srow // S.TILE
+                t = j * world + (world - 1 - r if j % 2 else r)
+                row = t * S.TILE + srow % S.TILE
+                if t >= t_all or row >= n:
+                    continue
+                c0 = cols[g] * S.TILE
+                cend = min(n, (t + 1) * S.TILE, c0 + wd)
+                if cend <= c0:
+                    continue
+                src = stage[world * off + r * cnt + srow * wd: world * off + r * cnt + srow * wd + cend - c0]
+                out[row, c0:cend] = src
+                if diag_add and c0 <= row < cend:
+                    out[row, row] += diag_add
 
-    def lml(self, dtype_code, n, y_ptr, eps_abs, df, scale):
+    def lml(self, dtype_code, n, y_ptr, df, scale):
         from oracle import nngp_oracle as O
         kl = np.tril(self.k)
-        self.ks = kl + np.tril(kl, -1).T
-        lp = O.mvn_logpdf(self.y, self.ks + eps_abs * np.eye(n))
+        self.ks = kl + np.tril(kl, -1).T                        # (the jitter is in it already: the scatter added it)
+        lp = O.mvn_logpdf(self.y, self.ks)
         return lp, 0.0, 0.0, 0
 
 
-def _pipelined_worker(rank, world, port, n, d, parts, q, with_ntk=False):
+def _cols_worker(rank, world, port, n, d, cols, q, with_ntk=False):
     import torch
     import torch.distributed as dist
     sys.path.insert(0, ROOT)
@@ -294,22 +321,24 @@ def _pipelined_worker(rank, world, port, n, d, parts, q, with_ntk=False):
     try:
         rng = np.random.default_rng(0)
         x = rng.standard_normal((n, d)); y = rng.standard_normal(n)
-        chunk = S.paired_chunk_elems(n, world)
-        mine = np.full(chunk, np.nan); stage = np.full(world * chunk, np.nan)
+        cols = cols or S.default_col_pieces(n, world)
+        elems = S.col_layout(n, world, cols)["elems"]
+        mine = np.full(elems, np.nan); stage = np.full(world * elems, np.nan)
         be = _CpuBackend(dist, torch, x, y, world, rank)
         spec = (0, 0, 2, 1.2, 0.3, 1.0)
         ntk = None
         if with_ntk:
             tk = np.full((n, n), np.nan)
-            ntk = (np.full(chunk, np.nan), np.full(world * chunk, np.nan), tk, n)
-        lp, _, _, info = S.lml_sharded_pipelined(be, 1, spec, None, n, d, d, None, rank, world, mine, stage, 1e-3, parts=parts, ntk=ntk)
-        # the driver's order: begin, then for every piece its build (if it adds rows) BEFORE its exchange, pieces in order
-        ex = [c[1] for c in be.calls if c[0] == "exchange"]
-        assert be.calls[0] == "begin" and ex == list(range(parts))
-        reuse = [c[2] for c in be.calls if c[0] == "build"]
-        assert reuse and reuse[0] is False and all(reuse[1:])       # x is padded once
+            ntk = (np.full(elems, np.nan), np.full(world * elems, np.nan), tk, n)
+        phases = []
+        lp, _, _, info = S.lml_sharded_cols(be, 1, spec, None, n, d, d, None, rank, world, mine, stage, 1e-3, cols=cols, ntk=ntk,
+                                            progress=phases.append)
+        # the driver's order: begin, ONE build, then the pieces in column order, then the factorisation
+        assert be.calls[0] == "begin" and be.calls[1][0] == "build"
+        assert [c[1] for c in be.calls[2:]] == list(range(len(cols) - 1))
+        assert phases[0] == "begin" and phases[1] == "build" and phases[-1] == "factor" and len(phases) == len(cols) + 2
         try:
-            S.lml_sharded_pipelined(be, 1, spec, None, n, d, d, None, rank, world + 1, mine, stage, 1e-3, parts=parts)
+            S.lml_sharded_cols(be, 1, spec, None, n, d, d, None, rank, world + 1, mine, stage, 1e-3, cols=cols)
             raised = False
         except RuntimeError:
             raised = True
@@ -319,10 +348,12 @@ def _pipelined_worker(rank, world, port, n, d, parts, q, with_ntk=False):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n,parts,with_ntk", [(300, 4, False), (513, 8, False), (200, 1, False), (300, 4, True)])
-def test_world_size_2_gloo_pipelined_driver_with_cpu_backend(n, parts, with_ntk):
-    """Two gloo processes run sharding.lml_sharded_pipelined itself -- the function bench.py --gpus N runs on the GPUs --
-    with the device steps replaced by a CPU backend: piece-wise build, piece-wise all-gather, scatter, head."""
+@pytest.mark.parametrize("n,cols,with_ntk", [(300, None, False), (513, [0, 2, 4, 5], False), (200, [0, 2], False),
+                                              (300, [0, 2, 3], True)])
+def test_world_size_2_gloo_column_first_driver_with_cpu_backend(n, cols, with_ntk):
+    """Two gloo processes run sharding.lml_sharded_cols itself -- the function bench.py --gpus N runs on the GPUs -- with the
+    device steps replaced by a CPU backend: one build per rank in the cyclic layout, an all-gather per column range, the
+    scatter (jitter on the diagonal), the head."""
     pytest.importorskip("torch")
     import torch.multiprocessing as mp
     from oracle import nngp_oracle as O
@@ -330,7 +361,7 @@ def test_world_size_2_gloo_pipelined_driver_with_cpu_backend(n, parts, with_ntk)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     d = 5
-    procs = [ctx.Process(target=_pipelined_worker, args=(r, 2, port, n, d, parts, q, with_ntk)) for r in range(2)]
+    procs = [ctx.Process(target=_cols_worker, args=(r, 2, port, n, d, cols, q, with_ntk)) for r in range(2)]
     for p in procs:
         p.start()
     k, lml, raised, tk = q.get(timeout=180)
@@ -340,13 +371,12 @@ def test_world_size_2_gloo_pipelined_driver_with_cpu_backend(n, parts, with_ntk)
     rng = np.random.default_rng(0)
     x = rng.standard_normal((n, d)); y = rng.standard_normal(n)
     ref = O.mlp_kernel(x, None, 2, "relu", 1.2, 0.3, 1.0)
-    assert np.allclose(k, ref, rtol=1e-12, atol=1e-14)
+    assert np.allclose(k, ref + 1e-3 * np.eye(n), rtol=1e-12, atol=1e-14)
     ref_lml = O.mvn_logpdf(y, ref + 1e-3 * np.eye(n))
     assert abs(lml - ref_lml) < 1e-9 * abs(ref_lml)
     assert raised            # a world the communicator does not have is refused
-    if with_ntk:             # BASELINE config 5: the NTK rides the same pipeline, piece by piece
+    if with_ntk:             # BASELINE config 5: the NTK rides the same exchange, column range by column range
         ref_t = O.mlp_kernel(x, None, 2, "relu", 1.2, 0.3, 1.0, get=("nngp", "ntk"))[1]
         rr, cc = np.indices((n, n))
-        own = cc < np.minimum(n, (rr // 128 + 1) * 128)
-        low = own & (cc <= rr)
+        low = cc <= rr
         assert np.allclose(tk[low], ref_t[low], rtol=1e-12, atol=1e-14)
