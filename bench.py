@@ -660,6 +660,96 @@ def measure_loss_grad(L, ctx, n, d, nl, act, steps, warmup):
                          "frac": flops / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS}}
 
 
+def measure_sweep(L, ctx, n, t, d, nl, act, steps=2):
+    """The reference's grid search (experiments/regression/find.py:134-199, its default grid: 3 w_std x 3 b_std x 11 eps x
+    3 alpha x 3 beta) on one synthetic data set of N training and T test points: 99 problems, two factorisations each.
+    Batched (sweeps.find_grid: smn_spr_predict_batch + smn_spr_loss_batch + smn_mixture_nll, grid.y = 99) beside the
+    same 198 factorisations issued one by one (smn_spr_predict + smn_spr_loss per cell: what a loop over the serial
+    entry points costs)."""
+    from smnngp import sweeps
+    rng = np.random.default_rng(0)
+    xh = rng.standard_normal((n, d)).astype(np.float32)
+    yh = np.sin(xh[:, 0]) + 0.1 * rng.standard_normal(n).astype(np.float32)
+    xth = rng.standard_normal((t, d)).astype(np.float32)
+    yth = np.sin(xth[:, 0])
+    ws, bs = (1.0, 1.4, 2.0), (0.0, 0.3, 1.0)
+    es = tuple(float("1e%d" % v) for v in range(-6, 5))
+    kw = dict(network="mlp", num_hiddens=nl, activation=act, w_std_list=ws, b_std_list=bs, eps_list=es,
+              alpha_list=(1.0, 2.0, 3.0), beta_list=(1.0, 2.0, 3.0), ctx=ctx)
+    x, xt = ctx.to_device(xh), ctx.to_device(xth)
+    y = ctx.to_device(yh.reshape(n, 1).astype(np.float32))
+    got = sweeps.find_grid(x, yh, xth, yth, **kw)                       # warm-up (workspaces, first-launch costs)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        got = sweeps.find_grid(x, yh, xth, yth, **kw)
+    ctx.synchronize()
+    total_ms = (time.perf_counter() - t0) / steps * 1e3
+    cells = [(w, b, e) for w in ws for b in bs for e in es]
+    wv, bv, ev = (np.array(v) for v in zip(*cells))
+    bkw = dict(network="mlp", num_hiddens=nl, activation=act, w_std=wv, b_std=bv, last_w_std=1.0)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        sweeps.predict_batch(ctx, x, y, xt, diag_reg=ev, on_device=True, **bkw)
+        sweeps.loss_batch(ctx, x, y, eps=ev, **bkw)
+    ctx.synchronize()
+    batch_ms = (time.perf_counter() - t0) / steps * 1e3
+    # the same 198 factorisations through the serial entry points
+    mean_d, cov_d = ctx.empty((t, 1), np.float32), ctx.empty((t, t), np.float32)
+    lp, quad, logdet, info = C.c_double(), C.c_double(), C.c_double(), C.c_int()
+
+    def serial():
+        for w, b, e in cells:
+            ctx.call("smn_spr_predict", L.F32, L.NET_MLP, L.ACT[act], nl, w, b, 1.0, x.ptr, n, d, xt.ptr, t, d, d, y.ptr, 1, e, 0.0,
+                     mean_d.ptr, cov_d.ptr, t, None, None, C.byref(info))
+            ctx.call("smn_spr_loss", L.F32, L.NET_MLP, L.ACT[act], nl, w, b, 1.0, x.ptr, n, d, d, y.ptr, e, 0.0, 1.0,
+                     C.byref(lp), C.byref(quad), C.byref(logdet), C.byref(info))
+    serial()
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    serial()
+    ctx.synchronize()
+    serial_ms = (time.perf_counter() - t0) * 1e3
+    nprob = 2 * len(cells)
+    flops = len(cells) * (2.0 * n ** 3 / 3.0 + float(n) * n * t + float(n) * t * t + 2.0 * (2 * n * n + 2 * n * t + t * t) * d)
+    return {"workload": "find_grid (find.py:134-199 default grid 3x3x11 x 3x3): N=%d T=%d d=%d L=%d %s f32, %d factorisations" % (n, t, d, nl, act, nprob),
+            "ms_per_sweep": total_ms, "device_batches_ms": batch_ms, "serial_calls_ms": serial_ms,
+            "speedup_vs_serial_calls": serial_ms / batch_ms, "problems_per_s": nprob / (batch_ms * 1e-3),
+            "value": flops / (batch_ms * 1e-3) / 1e9, "unit": "GFLOP/s",
+            "flops_note": "per cell 2 N^3/3 + N^2 T + N T^2 + the two Gram builds; batches only (the mixture kernel and the host tables are in ms_per_sweep)",
+            "finite_cells": int(np.isfinite(got["gnll"]).sum()), "best_gaussian": got["best_gaussian"], "best_student": got["best_student"]}
+
+
+def measure_small_n(L, ctx, n, d, nl, act, g, steps=20):
+    """The reference's training size (train.py:178-212: N = 245): G independent SPR.loss evaluations (a population of
+    hyper-parameter settings) as one batched call beside G serial calls."""
+    from smnngp import sweeps
+    rng = np.random.default_rng(0)
+    x = ctx.to_device(rng.standard_normal((n, d)).astype(np.float32))
+    y = ctx.to_device(rng.standard_normal((n, 1)).astype(np.float32))
+    wv = np.linspace(0.8, 2.0, g); bv = np.linspace(0.0, 1.0, g); ev = np.full(g, 1e-2)
+    kw = dict(network="mlp", num_hiddens=nl, activation=act, w_std=wv, b_std=bv, last_w_std=1.0, eps=ev)
+    sweeps.loss_batch(ctx, x, y, **kw)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        sweeps.loss_batch(ctx, x, y, **kw)
+    batch_us = (time.perf_counter() - t0) / steps * 1e6
+    lp, quad, logdet, info = C.c_double(), C.c_double(), C.c_double(), C.c_int()
+
+    def serial():
+        for w, b in zip(wv, bv):
+            ctx.call("smn_spr_loss", L.F32, L.NET_MLP, L.ACT[act], nl, w, b, 1.0, x.ptr, n, d, d, y.ptr, 1e-2, 0.0, 1.0,
+                     C.byref(lp), C.byref(quad), C.byref(logdet), C.byref(info))
+    serial()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        serial()
+    serial_us = (time.perf_counter() - t0) / 3 * 1e6
+    return {"workload": "%d x SPR.loss: N=%d d=%d L=%d %s f32 (train.py-sized problems)" % (g, n, d, nl, act),
+            "batched_us_per_problem": batch_us / g, "serial_us_per_problem": serial_us / g, "speedup": serial_us / batch_us,
+            "problems_per_s": g / (batch_us * 1e-6)}
+
+
 def other_workloads(L, ctx, budget_s=330.0):
     """BASELINE.json's other single-GPU configurations and the predictive path, measured in this process after the
     headline (each in its own try: a failing or skipped workload never breaks the bench line)."""
@@ -667,6 +757,8 @@ def other_workloads(L, ctx, budget_s=330.0):
     out = {}
     plan = [
         ("c2", lambda: measure_mlp_loss(L, ctx, 4096, 512, 3, "relu", "f32", 1e-3, 20, 3)),
+        ("sweep_n2048", lambda: measure_sweep(L, ctx, 2048, 256, 16, 4, "relu")),
+        ("batch_n245", lambda: measure_small_n(L, ctx, 245, 6, 2, "relu", 256)),
         ("predict_c4", lambda: measure_predict(L, ctx, 16384, 3072, 4, "relu", 2048, 3, 1)),
         ("grad_c4", lambda: measure_loss_grad(L, ctx, 16384, 3072, 4, "relu", 3, 1)),
         ("f64_n8192", lambda: measure_mlp_loss(L, ctx, 8192, 3072, 4, "relu", "f64", 1e-6, 5, 1)),

@@ -204,6 +204,44 @@ int smn_spr_predict(smn_ctx* ctx, int dtype, int net, int act, int num_hiddens,
                     void* mean_d, void* cov_d, int64_t ldcov,
                     double* quad_h, double* logdet_h, int* info_h);
 
+/* ---- batched small problems: G evaluations on ONE data set in one sequence of launches (grid.y = G) ----
+ * The reference's real workloads are small and many: experiments/regression/find.py:134-199 factors the kernel of one data
+ * set 2 x 99 times under a grid of (w_std, b_std, eps), train.py:178-212 takes thousands of steps at N = 245, where one
+ * SPR.loss occupies two workgroups of a 256-CU chip.  These calls run nprob problems of identical shape -- same x, y, net,
+ * act and depth; per-problem w_std[], b_std[], last_w_std[] and diagonal shift (host arrays of nprob doubles) -- through
+ * the fused build, the factorisation and the read-out together; each problem's result is bit-identical to the serial call.
+ *   smn_spr_loss_batch     nprob x smn_spr_loss: eps_abs[], df[] (NULL: Gaussian), scale[] -> logpdf_h[], quad_h[], logdet_h[],
+ *                          info_h[] (any output may be NULL)
+ *   smn_spr_predict_batch  nprob x smn_spr_predict: ridge_rel[], ridge_abs[] (NULL: 0) -> mean_d [nprob,t,c], cov_d
+ *                          [nprob,t,ldcov] and / or var_d [nprob,t] = diag(cov) (what find.py:50-55 uses; either may be
+ *                          NULL), quad_h [nprob,c], logdet_h[], info_h[]
+ * Batches whose workspaces (nprob x (n_pad + (t+c)_pad)^2 elements) exceed 48 GB run in chunks (smn_debug_batch_bytes: test
+ * hook that sets that budget). */
+int smn_spr_loss_batch(smn_ctx* ctx, int dtype, int net, int act, int num_hiddens, int nprob,
+                       const double* w_std, const double* b_std, const double* last_w_std,
+                       const void* x_d, int64_t n, int64_t ldx, int64_t d, const void* y_d,
+                       const double* eps_abs, const double* df, const double* scale,
+                       double* logpdf_h, double* quad_h, double* logdet_h, int* info_h);
+int smn_debug_batch_bytes(smn_ctx* ctx, size_t bytes);
+int smn_spr_predict_batch(smn_ctx* ctx, int dtype, int net, int act, int num_hiddens, int nprob,
+                          const double* w_std, const double* b_std, const double* last_w_std,
+                          const void* x_d, int64_t n, int64_t ldx, const void* xt_d, int64_t t, int64_t ldxt,
+                          int64_t d, const void* y_d, int64_t c, const double* ridge_rel, const double* ridge_abs,
+                          void* mean_d, void* cov_d, int64_t ldcov, void* var_d,
+                          double* quad_h, double* logdet_h, int* info_h);
+
+/* ---- predictive NLL under a sampled scale mixture (experiments/regression/find.py:165-187) ----
+ * For nprob problems with posterior mean_d / var_d [nprob,t] (normalised units; smn_spr_predict_batch), quad_h / logdet_h [nprob]
+ * (smn_spr_loss_batch) and nmix proposals of nsamples sigma^2 draws each (sample_q_h [nmix,nsamples]; ratio_h = prior /
+ * proposal density per draw, NULL = 1, which is what find.py:168-169 evaluates to):
+ *   tnll_h[p, m] = - mean_t logsumexp_s [ log(w~_s + 1e-24) + log N(y_test_t; mean_t y_std + y_mean, sqrt(q_s var_t) y_std) ]
+ * with w~ the self-normalised weights of log p(y_train | q_s) = -(n/2) log 2 pi - logdet/2 - quad/(2 q_s) - (n/2) log q_s.
+ * skip_h[p] != 0 (may be NULL): NaN for that problem.  fp64 arithmetic throughout; y_test_h in original units. */
+int smn_mixture_nll(smn_ctx* ctx, int dtype, int nprob, int64_t t, const void* mean_d, const void* var_d,
+                    const double* quad_h, const double* logdet_h, const int* skip_h, const double* y_test_h,
+                    double y_mean, double y_std, int64_t n, int nmix, int nsamples, const double* sample_q_h,
+                    const double* ratio_h, double* tnll_h);
+
 /* ---- hyper-parameter gradients of the log-marginal likelihood ----
  * What objax.GradValues(model.loss, vars) supplies to experiments/regression/train.py:61-67.
  * With K~ = K(w_std, b_std, last_w_std) + eps I, alpha = K~^-1 y and G = coef * alpha alpha^T - K~^-1:

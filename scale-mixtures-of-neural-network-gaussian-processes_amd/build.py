@@ -10,7 +10,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["api.hip", "kernel_build.hip", "cholesky.hip", "heads.hip", "comm.hip", "cnn.hip", "cnn_resnet.hip", "grad.hip"]
+SOURCES = ["api.hip", "kernel_build.hip", "cholesky.hip", "heads.hip", "comm.hip", "cnn.hip", "cnn_resnet.hip", "grad.hip", "mixture.hip"]
 # -fno-slp-vectorize: hipcc's SLP pass packs adjacent f32 ops into v_pk_*_f32, which on gfx950 issue slower
 # than the two plain ops they replace (MI355X_MICROARCH.md, "packed f32 VALU"); measured here: recursion
 # kernel -9 %, panel kernel -8 % with packing off (profiles/README.md).

@@ -163,9 +163,13 @@ __global__ void __launch_bounds__(panel_threads(XRV)) panel_kernel(T* __restrict
                                                                      int64_t rbeg, int64_t n_total, int prefactored,
                                                                      double* __restrict__ logdet,
                                                                      int* __restrict__ info, T* __restrict__ ldiag_out,
-                                                                     int64_t id0, int64_t id1) {
+                                                                     int64_t id0, int64_t id1, int64_t bstride, int64_t lstride) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int XR = XRV, NT = panel_threads(XRV), LD = PanelCfg<T>::LD;
+  if (bstride) {   // batched factorisation: problem blockIdx.y has its own matrix, scalars and side buffer
+    a += (int64_t)blockIdx.y * bstride; logdet += blockIdx.y; info += blockIdx.y;
+    if (ldiag_out) ldiag_out += (int64_t)blockIdx.y * lstride;
+  }
   constexpr int VEC = 16 / sizeof(T);
   using vec_t = typename Mfma<T>::vec_t;
   T* S = reinterpret_cast<T*>(smem);        // [PB + XR][LD]
@@ -397,9 +401,13 @@ __global__ void __launch_bounds__(2 * panel_threads(XRV)) panelr_kernel(T* __res
                                                                           int64_t rbeg, int64_t n_total,
                                                                           double* __restrict__ logdet,
                                                                           int* __restrict__ info, T* __restrict__ ldiag_out,
-                                                                          int64_t id0, int64_t id1) {
+                                                                          int64_t id0, int64_t id1, int64_t bstride, int64_t lstride) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int XR = XRV, NTV = panel_threads(XRV), LD = PanelCfg<T>::LD;
+  if (bstride) {   // batched factorisation: problem blockIdx.y has its own matrix, scalars and side buffer
+    a += (int64_t)blockIdx.y * bstride; logdet += blockIdx.y; info += blockIdx.y;
+    if (ldiag_out) ldiag_out += (int64_t)blockIdx.y * lstride;
+  }
   constexpr int VEC = 16 / sizeof(T);
   constexpr int CB = 16, NB = PB / CB, VPC = CB / VEC, ROWS = PB + XR;
   using vec_t = typename Mfma<T>::vec_t;
@@ -704,6 +712,7 @@ template <typename T>
 struct UpdArgs {
   T* a; int64_t lda; int64_t r0, c0, k0; int K; int tiles_n; int lower;
   int use_map; TileMap map;   // XCD-aware patch order (gemm_nt.hpp) instead of the linear one
+  int64_t bstride;            // batched factorisation: problem blockIdx.y works on a + blockIdx.y * bstride (0: one problem)
 };
 
 template <typename T>
@@ -763,6 +772,7 @@ __device__ __forceinline__ void upd_decode_half(const UpdArgs<T>& u, int tl, int
 template <typename T, int TAG, int BM = kTile, int BN = kTile>
 __global__ void __launch_bounds__(256, BN == 64 ? 4 : (BM == 64 ? (sizeof(T) == 8 ? 2 : 3) : 2)) update_kernel(UpdArgs<T> u) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  u.a += (int64_t)blockIdx.y * u.bstride;
   using Tile = TileNT<T, BM, BN, SMN_STAGES>;
   using M = typename Tile::M;
   static_assert(BN == kTile || (BM == 64 && BN == 64), "tile shapes: 128x128, 64x128, 64x64");
@@ -977,11 +987,13 @@ int launch_update(smn_ctx* ctx, hipStream_t st, T* a, int64_t lda, int64_t r0, i
     lower = 1;
     tiles_n = tiles_m;
   }
-  UpdArgs<T> u{a, lda, r0, c0, k0, (int)K, (int)tiles_n, lower, 0, TileMap::make(tiles_m, tiles_n, lower == 1)};
+  UpdArgs<T> u{a, lda, r0, c0, k0, (int)K, (int)tiles_n, lower, 0, TileMap::make(tiles_m, tiles_n, lower == 1),
+               ctx->batch_logdet ? ctx->batch_stride : 0};
+  const unsigned gy = (unsigned)(ctx->batch_logdet ? ctx->batch : 1);
   int64_t nt = lower == 1   ? tiles_m * (tiles_m + 1) / 2
                : lower == 2 ? tiles_n * (tiles_n + 1) / 2 + (tiles_m - tiles_n) * tiles_n
                             : tiles_m * tiles_n;
-  ctx->prof_flops[tag ? PROF_TRAIL : PROF_STRIP] += 2.0 * kTile * kTile * (double)K * (double)nt;   // executed: whole tiles
+  ctx->prof_flops[tag ? PROF_TRAIL : PROF_STRIP] += 2.0 * kTile * kTile * (double)K * (double)nt * gy;   // executed: whole tiles
   if (ctx->xcd_map && nt >= 512 && lower != 2) {   // small launches do not fill the XCDs anyway
     u.use_map = 1;
     nt = u.map.grid;
@@ -990,7 +1002,7 @@ int launch_update(smn_ctx* ctx, hipStream_t st, T* a, int64_t lda, int64_t r0, i
   if constexpr (sizeof(T) == 4) {
     // CUs this stream may use: the bulk stream of the look-ahead is masked off the chain's CUs
     const int cus = (st == ctx->stream_bulk && st != nullptr) ? ctx->num_cu - ctx->chain_cus : ctx->num_cu;
-    if (tag == 1 && lower && !u.use_map && nt > 2 * cus && K <= kPersistMaxK) {
+    if (tag == 1 && lower && !u.use_map && gy == 1 && nt > 2 * cus && K <= kPersistMaxK) {
       // persistent walk over the lower tiles, two workgroups per CU
       const size_t plds = TileNT<T, kTile, kTile, 2>::LDS_BYTES;
       ProfScope ps(ctx, PROF_TRAIL, st);
@@ -1005,10 +1017,10 @@ int launch_update(smn_ctx* ctx, hipStream_t st, T* a, int64_t lda, int64_t r0, i
     constexpr size_t qlds = TileNT<T, 64, 64, SMN_STAGES>::LDS_BYTES;
     if (tag) {
       auto kern = update_kernel<T, 1, 64, 64>;
-      hipLaunchKernelGGL(kern, dim3((unsigned)(4 * nt)), dim3(256), qlds, st, u);
+      hipLaunchKernelGGL(kern, dim3((unsigned)(4 * nt), gy), dim3(256), qlds, st, u);
     } else {
       auto kern = update_kernel<T, 0, 64, 64>;
-      hipLaunchKernelGGL(kern, dim3((unsigned)(4 * nt)), dim3(256), qlds, st, u);
+      hipLaunchKernelGGL(kern, dim3((unsigned)(4 * nt), gy), dim3(256), qlds, st, u);
     }
     SMN_CHECK_LAUNCH(ctx);
     return SMN_OK;
@@ -1022,10 +1034,10 @@ int launch_update(smn_ctx* ctx, hipStream_t st, T* a, int64_t lda, int64_t r0, i
     constexpr size_t hlds = TileNT<T, 64, kTile, SMN_STAGES>::LDS_BYTES;
     if (tag) {
       auto kern = update_kernel<T, 1, 64>;
-      hipLaunchKernelGGL(kern, dim3((unsigned)nh), dim3(256), hlds, st, u);
+      hipLaunchKernelGGL(kern, dim3((unsigned)nh, gy), dim3(256), hlds, st, u);
     } else {
       auto kern = update_kernel<T, 0, 64>;
-      hipLaunchKernelGGL(kern, dim3((unsigned)nh), dim3(256), hlds, st, u);
+      hipLaunchKernelGGL(kern, dim3((unsigned)nh, gy), dim3(256), hlds, st, u);
     }
     SMN_CHECK_LAUNCH(ctx);
     return SMN_OK;
@@ -1034,10 +1046,10 @@ int launch_update(smn_ctx* ctx, hipStream_t st, T* a, int64_t lda, int64_t r0, i
     ProfScope ps(ctx, tag ? PROF_TRAIL : PROF_STRIP, st);
     if (tag) {
       auto kern = update_kernel<T, 1>;
-      hipLaunchKernelGGL(kern, dim3((unsigned)nt), dim3(256), lds, st, u);
+      hipLaunchKernelGGL(kern, dim3((unsigned)nt, gy), dim3(256), lds, st, u);
     } else {
       auto kern = update_kernel<T, 0>;
-      hipLaunchKernelGGL(kern, dim3((unsigned)nt), dim3(256), lds, st, u);
+      hipLaunchKernelGGL(kern, dim3((unsigned)nt, gy), dim3(256), lds, st, u);
     }
   }
   SMN_CHECK_LAUNCH(ctx);
@@ -1049,12 +1061,17 @@ int launch_panel_x(smn_ctx* ctx, hipStream_t st, T* a, int64_t lda, int64_t j0, 
   const int64_t rbeg = j0 + PB;
   const int64_t below = n_total - rbeg;
   const unsigned grid = below > 0 ? (unsigned)((below + XRV - 1) / XRV) : 1u;
+  const bool batched = ctx->batch_logdet != nullptr;   // (a batch of ONE problem still keeps its scalars in the batch arrays)
+  const unsigned gy = (unsigned)(batched ? ctx->batch : 1);
+  const int64_t bs = batched ? ctx->batch_stride : 0, ls = batched ? ctx->batch_ldiag_stride : 0;
+  double* logdet = batched ? ctx->batch_logdet : ctx->d_scal;
+  int* info = batched ? ctx->batch_info : ctx->d_info;
   if (ctx->panel_leaf && !prefactored) {
     ProfScope ps(ctx, PROF_PANEL, st);
     T* ldiag = reinterpret_cast<T*>(ctx->ws[3]) + (j0 / PB) * (int64_t)(PB * PB);
     auto kernr = panelr_kernel<T, XRV>;
-    hipLaunchKernelGGL(kernr, dim3(grid), dim3(2 * panel_threads(XRV)), panelr_lds_bytes<T>(XRV), st, a, lda, j0, rbeg, n_total,
-                       ctx->d_scal, ctx->d_info, ldiag, ctx->chol_id0, ctx->chol_id1);
+    hipLaunchKernelGGL(kernr, dim3(grid, gy), dim3(2 * panel_threads(XRV)), panelr_lds_bytes<T>(XRV), st, a, lda, j0, rbeg, n_total,
+                       logdet, info, ldiag, ctx->chol_id0, ctx->chol_id1, bs, ls);
     SMN_CHECK_LAUNCH(ctx);
     return SMN_OK;
   }
@@ -1062,8 +1079,8 @@ int launch_panel_x(smn_ctx* ctx, hipStream_t st, T* a, int64_t lda, int64_t j0, 
   {
     ProfScope ps(ctx, PROF_PANEL, st);
     T* ldiag = reinterpret_cast<T*>(ctx->ws[3]) + (j0 / PB) * (int64_t)(PB * PB);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(panel_threads(XRV)), panel_lds_bytes<T>(XRV), st, a, lda, j0, rbeg, n_total,
-                       prefactored, ctx->d_scal, ctx->d_info, ldiag, ctx->chol_id0, ctx->chol_id1);
+    hipLaunchKernelGGL(kern, dim3(grid, gy), dim3(panel_threads(XRV)), panel_lds_bytes<T>(XRV), st, a, lda, j0, rbeg, n_total,
+                       prefactored, logdet, info, ldiag, ctx->chol_id0, ctx->chol_id1, bs, ls);
   }
   SMN_CHECK_LAUNCH(ctx);
   return SMN_OK;
@@ -1118,7 +1135,8 @@ int cholesky_t(smn_ctx* ctx, T* a, int64_t n_total, int64_t n_factor, int64_t ld
                double ridge_rel, bool keep_factor) {
   SMN_TRY(set_lds_attrs<T>(ctx));
   void* side = nullptr;   // factored diagonal blocks, [n_factor/128][128*128]
-  SMN_TRY(smn_workspace(ctx, 3, sizeof(T) * (size_t)n_factor * PB, &side));
+  SMN_TRY(smn_workspace(ctx, 3, sizeof(T) * (size_t)n_factor * PB * (size_t)(ctx->batch_logdet ? ctx->batch : 1), &side));
+  ctx->batch_ldiag_stride = n_factor * PB;
   hipStream_t st = ctx->stream;
   if (!ctx->chol_prepped) hipLaunchKernelGGL(init_scalars_kernel, dim3(1), dim3(1), 0, st, ctx->d_scal, ctx->d_info);
   if (!ctx->chol_prepped && n_shift > 0 && (jitter_abs != 0.0 || ridge_rel != 0.0)) {
@@ -1251,6 +1269,7 @@ int cholesky_t(smn_ctx* ctx, T* a, int64_t n_total, int64_t n_factor, int64_t ld
       hip_ok(hipStreamWaitEvent(st, ctx->ev_b, 0));
     }
   }
+  if (rc == SMN_OK && keep_factor && ctx->batch_logdet) rc = smn_fail(ctx, SMN_ENOTSUP, "cholesky: keep_factor in a batched factorisation");
   if (rc == SMN_OK && keep_factor) {
     hipLaunchKernelGGL(copy_diag_kernel<T>, dim3((unsigned)(n_factor / PB)), dim3(1024), 0, st, a, lda,
                        static_cast<const T*>(side));
@@ -1311,13 +1330,13 @@ int solve_rows_padded(smn_ctx* ctx, int dtype, void* a, int64_t n_total, int64_t
         const unsigned grid = (unsigned)((n_total - n_factor + XR - 1) / XR);
         hipLaunchKernelGGL(panel_kernel<double>, dim3(grid), dim3(panel_threads(XR)),
                            panel_lds_bytes<double>(), st, static_cast<double*>(a), lda, js, n_factor,
-                           n_total, 1, ctx->d_scal, ctx->d_info, static_cast<double*>(nullptr), (int64_t)-1, (int64_t)-1);
+                           n_total, 1, ctx->d_scal, ctx->d_info, static_cast<double*>(nullptr), (int64_t)-1, (int64_t)-1, (int64_t)0, (int64_t)0);
       } else {
         constexpr int XR = PanelCfg<float>::XR;
         const unsigned grid = (unsigned)((n_total - n_factor + XR - 1) / XR);
         hipLaunchKernelGGL(panel_kernel<float>, dim3(grid), dim3(panel_threads(XR)),
                            panel_lds_bytes<float>(), st, static_cast<float*>(a), lda, js, n_factor,
-                           n_total, 1, ctx->d_scal, ctx->d_info, static_cast<float*>(nullptr), (int64_t)-1, (int64_t)-1);
+                           n_total, 1, ctx->d_scal, ctx->d_info, static_cast<float*>(nullptr), (int64_t)-1, (int64_t)-1, (int64_t)0, (int64_t)0);
       }
       SMN_CHECK_LAUNCH(ctx);
     }

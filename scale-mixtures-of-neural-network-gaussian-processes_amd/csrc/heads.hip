@@ -13,6 +13,8 @@
 //   NNGPKernel.predict            spax/kernels.py:29-32  (neural_tangents gradient_descent_mse_ensemble)
 //   the quadratic form of StudentTLikelihood.logpdf      spax/likelihoods.py:60-61
 // The closed-form log-pdf arithmetic on the resulting scalars is done on the host (lgamma etc.).
+#include <algorithm>
+#include <climits>
 #include <cmath>
 #include <vector>
 
@@ -52,7 +54,8 @@ double logpdf_from(double quad, double logdet, int64_t n, double df, double scal
 
 // Fused build of the augmented matrix straight from the inputs.
 int aug_build(smn_ctx* ctx, const BuildSpec& spec, const Aug& g, const void* x, int64_t ldx, const void* xt,
-              int64_t ldxt, int64_t d) {
+              int64_t ldxt, int64_t d, int nbatch = 0, const double* bw = nullptr, const double* bb = nullptr,
+              const double* blw = nullptr) {
   const int64_t kp = k_pad(spec.dtype, d);
   void* xs = nullptr;
   SMN_TRY(smn_workspace(ctx, 0, g.es * (size_t)kp * (size_t)g.n_total + sizeof(double) * (size_t)g.n_total, &xs));
@@ -71,6 +74,7 @@ int aug_build(smn_ctx* ctx, const BuildSpec& spec, const Aug& g, const void* x, 
   c.nv0 = g.n; c.aug0 = g.n_pad; c.nv1 = g.t;
   c.get_mask = SMN_GET_NNGP;
   c.out_k = g.a; c.ldo = g.lda;
+  c.nbatch = nbatch; c.bw = bw; c.bb = bb; c.blw = blw; c.out_bs = g.n_total * g.lda;   // batched: problem b at a + b * n_total^2
   return run_build(ctx, c);
 }
 
@@ -515,6 +519,216 @@ extern "C" int smn_spr_loss(smn_ctx* ctx, int dtype, int net, int act, int num_h
   if (logdet_h) *logdet_h = ld;
   if (info_h) *info_h = info;
   return SMN_OK;
+}
+
+// ---- batched small problems (experiments/regression/find.py:134-199: 99 factorisations of one data set under a grid of
+// (w_std, b_std, eps); train.py:178-212: thousands of steps at N = 245).  One SPR.loss at N = 245 is two workgroups on a
+// 256-CU chip and a 2048-point one a hundred; G problems of identical shape -- same x, y, net, depth; their own w_std,
+// b_std, last_w_std and diagonal shift -- run as ONE sequence of launches with grid.y = G: the fused build (per-problem
+// layer program and tables), the prep, every panel / update launch of the factorisation, the read-out.  Problem b lives
+// at workspace + b * n_total^2; per-problem logdet / info / quadratic forms come back in one copy.  Each problem executes
+// exactly the arithmetic of the serial call (same kernels, same tiles, same order): bit-identical results.
+namespace {
+
+template <typename T>
+__global__ void batch_trace_kernel(const T* __restrict__ a, int64_t lda, int64_t bstride, int64_t n, double* __restrict__ out) {
+  __shared__ double red[256];   // one block per problem; the deterministic tree of diag_trace_kernel (cholesky.hip)
+  a += (int64_t)blockIdx.x * bstride;
+  double s = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += 256) s += (double)a[i * lda + i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[blockIdx.x] = red[0];
+}
+
+// aug_prep_kernel / diag_shift_kernel per problem: right-hand-side rows, diagonal shift abs[b] + rel[b] tr / n, scalar reset
+template <typename T>
+__global__ void batch_prep_kernel(T* __restrict__ a, int64_t lda, int64_t bstride, int64_t row0, int64_t ncols,
+                                  const T* __restrict__ y, int64_t n, int64_t c, int64_t ldy, int64_t n_shift,
+                                  const double* __restrict__ shift_abs, const double* __restrict__ ridge_rel,
+                                  const double* __restrict__ trace, double* __restrict__ logdet, int* __restrict__ info) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t k = blockIdx.y, b = blockIdx.z;
+  if (i >= ncols || k >= c) return;
+  a += b * bstride;
+  a[(row0 + k) * lda + i] = i < n ? y[i * ldy + k] : T(0);
+  if (k == 0) {
+    if (i < n_shift) {
+      const double rel = ridge_rel ? ridge_rel[b] : 0.0;
+      const double sh = shift_abs[b] + (rel != 0.0 ? rel * trace[b] / (double)n_shift : 0.0);
+      if (sh != 0.0) a[i * lda + i] = (T)((double)a[i * lda + i] + sh);
+    }
+    if (i == 0) {
+      logdet[b] = 0.0;
+      info[b] = INT_MAX;
+    }
+  }
+}
+
+// extract_posterior_kernel per problem; res[b] = {logdet, info, quad[0..c)}
+template <typename T>
+__global__ void batch_extract_kernel(const T* __restrict__ a, int64_t lda, int64_t bstride, int64_t aug0, int64_t t, int64_t c,
+                                     T* __restrict__ mean, T* __restrict__ cov, int64_t ldcov, T* __restrict__ var,
+                                     double* __restrict__ res, const double* __restrict__ logdet, const int* __restrict__ info) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t b = blockIdx.z;
+  a += b * bstride;
+  for (int64_t i = blockIdx.y; i <= t; i += gridDim.y)
+    if (i < t) {
+      if (j < t && cov) {
+        const int64_t hi = i > j ? i : j, lo = i > j ? j : i;
+        cov[(b * t + i) * ldcov + j] = a[(aug0 + hi) * lda + aug0 + lo];
+      }
+      if (j == 0 && var) var[b * t + i] = a[(aug0 + i) * lda + aug0 + i];
+      if (j < c && mean) mean[(b * t + i) * c + j] = -a[(aug0 + t + j) * lda + aug0 + i];
+    } else {
+      if (j < c) res[b * (2 + c) + 2 + j] = -(double)a[(aug0 + t + j) * lda + aug0 + t + j];
+      if (j == 0) {
+        res[b * (2 + c)] = logdet[b];
+        res[b * (2 + c) + 1] = (double)info[b];
+      }
+    }
+}
+
+
+int spr_batch(smn_ctx* ctx, const char* who, int dtype, int net, int act, int num_hiddens, int nprob, const double* w_std,
+              const double* b_std, const double* last_w_std, const void* x_d, int64_t n, int64_t ldx, const void* xt_d,
+              int64_t t, int64_t ldxt, int64_t d, const void* y_d, int64_t c, const double* ridge_rel, const double* shift_abs,
+              void* mean_d, void* cov_d, int64_t ldcov, void* var_d, double* quad_h, double* logdet_h, int* info_h) {
+  if (dtype != SMN_F32 && dtype != SMN_F64) return smn_fail(ctx, SMN_EINVAL, "bad dtype");
+  if (nprob <= 0 || !w_std || !b_std || !last_w_std || !shift_abs) return smn_fail(ctx, SMN_EINVAL, "%s: empty batch or null parameter array", who);
+  if (n <= 0 || d <= 0 || t < 0 || c <= 0) return smn_fail(ctx, SMN_EINVAL, "%s: bad sizes", who);
+  if (c > 48) return smn_fail(ctx, SMN_ENOTSUP, "more than 48 output columns");
+  if (cov_d && ldcov < t) return smn_fail(ctx, SMN_EINVAL, "%s: ldcov < t", who);
+  const size_t es = dtype_size(dtype);
+  Aug g;
+  g.n = n; g.t = t; g.c = c;
+  g.n_pad = round_up(n, kTile);
+  g.n_total = g.n_pad + round_up(t + c, kTile);
+  g.lda = g.n_total;
+  g.es = es;
+  const size_t per = es * (size_t)g.n_total * (size_t)g.n_total;
+  int chunk = (int)std::min<size_t>((size_t)nprob, std::max<size_t>(1, ctx->batch_bytes / per));
+  if (chunk > 65535) chunk = 65535;   // grid.y / grid.z
+  SMN_TRY(smn_workspace(ctx, 2, per * (size_t)chunk, &g.a));
+  // per-problem scalars: shift_abs, ridge_rel, trace, logdet (doubles), res [2 + c], info (ints)
+  const size_t nd = (size_t)chunk * (4 + 2 + (size_t)c);
+  void* sv = nullptr;
+  SMN_TRY(smn_workspace(ctx, 8, sizeof(double) * nd + sizeof(int) * (size_t)chunk, &sv));
+  double* sh_d = static_cast<double*>(sv);
+  double* rel_d = sh_d + chunk;
+  double* tr_d = rel_d + chunk;
+  double* ld_d = tr_d + chunk;
+  double* res_d = ld_d + chunk;
+  int* info_d = reinterpret_cast<int*>(res_d + (size_t)chunk * (2 + (size_t)c));
+  std::vector<double> res_h((size_t)chunk * (2 + (size_t)c));
+  const int64_t bstride = g.n_total * g.lda;
+  BuildSpec spec{dtype, net, act, num_hiddens, w_std[0], b_std[0], last_w_std[0]};
+  for (int p0 = 0; p0 < nprob; p0 += chunk) {
+    const int nb = std::min(chunk, nprob - p0);
+    SMN_TRY(aug_build(ctx, spec, g, x_d, ldx, t > 0 ? xt_d : x_d, t > 0 ? ldxt : ldx, d, nb, w_std + p0, b_std + p0, last_w_std + p0));
+    SMN_HIP(ctx, hipMemcpyAsync(sh_d, shift_abs + p0, sizeof(double) * (size_t)nb, hipMemcpyHostToDevice, ctx->stream));
+    if (ridge_rel) {
+      SMN_HIP(ctx, hipMemcpyAsync(rel_d, ridge_rel + p0, sizeof(double) * (size_t)nb, hipMemcpyHostToDevice, ctx->stream));
+      if (dtype == SMN_F64)
+        hipLaunchKernelGGL(batch_trace_kernel<double>, dim3((unsigned)nb), dim3(256), 0, ctx->stream, static_cast<const double*>(g.a), g.lda, bstride, n, tr_d);
+      else
+        hipLaunchKernelGGL(batch_trace_kernel<float>, dim3((unsigned)nb), dim3(256), 0, ctx->stream, static_cast<const float*>(g.a), g.lda, bstride, n, tr_d);
+    }
+    {
+      dim3 gp((unsigned)((g.n_total + 255) / 256), (unsigned)c, (unsigned)nb);
+      if (dtype == SMN_F64)
+        hipLaunchKernelGGL(batch_prep_kernel<double>, gp, dim3(256), 0, ctx->stream, static_cast<double*>(g.a), g.lda, bstride, g.n_pad + t, g.n_total,
+                           static_cast<const double*>(y_d), n, c, c, n, sh_d, ridge_rel ? rel_d : nullptr, tr_d, ld_d, info_d);
+      else
+        hipLaunchKernelGGL(batch_prep_kernel<float>, gp, dim3(256), 0, ctx->stream, static_cast<float*>(g.a), g.lda, bstride, g.n_pad + t, g.n_total,
+                           static_cast<const float*>(y_d), n, c, c, n, sh_d, ridge_rel ? rel_d : nullptr, tr_d, ld_d, info_d);
+    }
+    SMN_CHECK_LAUNCH(ctx);
+    ctx->batch = nb; ctx->batch_stride = bstride; ctx->batch_logdet = ld_d; ctx->batch_info = info_d;
+    ctx->chol_prepped = true;
+    const int crc = cholesky_padded(ctx, dtype, g.a, g.n_total, g.n_pad, g.lda, n, 0.0, 0.0, false);
+    ctx->chol_prepped = false;
+    ctx->batch = 1; ctx->batch_stride = 0; ctx->batch_logdet = nullptr; ctx->batch_info = nullptr;
+    SMN_TRY(crc);
+    {
+      const int64_t w = std::max<int64_t>(std::max(t, c), 1);
+      dim3 ge((unsigned)((w + 255) / 256), (unsigned)std::min<int64_t>(t + 1, 4096), (unsigned)nb);
+      char* mean_p = mean_d ? static_cast<char*>(mean_d) + es * (size_t)p0 * (size_t)t * (size_t)c : nullptr;
+      char* cov_p = cov_d ? static_cast<char*>(cov_d) + es * (size_t)p0 * (size_t)t * (size_t)ldcov : nullptr;
+      char* var_p = var_d ? static_cast<char*>(var_d) + es * (size_t)p0 * (size_t)t : nullptr;
+      if (dtype == SMN_F64)
+        hipLaunchKernelGGL(batch_extract_kernel<double>, ge, dim3(256), 0, ctx->stream, static_cast<const double*>(g.a), g.lda, bstride, g.n_pad, t, c,
+                           reinterpret_cast<double*>(mean_p), reinterpret_cast<double*>(cov_p), ldcov, reinterpret_cast<double*>(var_p), res_d, ld_d, info_d);
+      else
+        hipLaunchKernelGGL(batch_extract_kernel<float>, ge, dim3(256), 0, ctx->stream, static_cast<const float*>(g.a), g.lda, bstride, g.n_pad, t, c,
+                           reinterpret_cast<float*>(mean_p), reinterpret_cast<float*>(cov_p), ldcov, reinterpret_cast<float*>(var_p), res_d, ld_d, info_d);
+    }
+    SMN_CHECK_LAUNCH(ctx);
+    SMN_HIP(ctx, hipMemcpyAsync(res_h.data(), res_d, sizeof(double) * (size_t)nb * (2 + (size_t)c), hipMemcpyDeviceToHost, ctx->stream));
+    SMN_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int b = 0; b < nb; ++b) {
+      const double* r = &res_h[(size_t)b * (2 + (size_t)c)];
+      int info = (int)r[1];
+      if (info == INT_MAX) info = 0;
+      if (info_h) info_h[p0 + b] = info;
+      if (logdet_h) logdet_h[p0 + b] = info ? std::nan("") : r[0];
+      for (int64_t k = 0; k < c && quad_h; ++k) quad_h[(size_t)(p0 + b) * (size_t)c + (size_t)k] = info ? std::nan("") : r[2 + k];
+    }
+  }
+  return SMN_OK;
+}
+
+}  // namespace
+
+// Test hook: the workspace budget of one batched pass (default 48 GB; larger batches run in chunks of what fits).
+extern "C" int smn_debug_batch_bytes(smn_ctx* ctx, size_t bytes) {
+  if (!ctx || bytes == 0) return SMN_EINVAL;
+  ctx->batch_bytes = bytes;
+  return SMN_OK;
+}
+
+extern "C" int smn_spr_loss_batch(smn_ctx* ctx, int dtype, int net, int act, int num_hiddens, int nprob, const double* w_std,
+                                  const double* b_std, const double* last_w_std, const void* x_d, int64_t n, int64_t ldx,
+                                  int64_t d, const void* y_d, const double* eps_abs, const double* df, const double* scale,
+                                  double* logpdf_h, double* quad_h, double* logdet_h, int* info_h) {
+  if (!ctx || !x_d || !y_d) return SMN_EINVAL;
+  SMN_ENTER(ctx);
+  if (nprob <= 0 || !eps_abs) return smn_fail(ctx, SMN_EINVAL, "smn_spr_loss_batch: empty batch or null eps_abs");
+  for (int b = 0; b < nprob && df; ++b)
+    if (df[b] > 0.0 && !(scale && scale[b] > 0.0)) return smn_fail(ctx, SMN_EINVAL, "smn_spr_loss_batch: scale must be > 0");
+  std::vector<double> quad((size_t)nprob), ld((size_t)nprob);
+  std::vector<int> info((size_t)nprob);
+  SMN_TRY(spr_batch(ctx, "smn_spr_loss_batch", dtype, net, act, num_hiddens, nprob, w_std, b_std, last_w_std, x_d, n, ldx, nullptr, 0, 0, d,
+                    y_d, 1, nullptr, eps_abs, nullptr, nullptr, 0, nullptr, quad.data(), ld.data(), info.data()));
+  for (int b = 0; b < nprob; ++b) {
+    if (logpdf_h) logpdf_h[b] = logpdf_from(quad[(size_t)b], ld[(size_t)b], n, df ? df[b] : 0.0, scale ? scale[b] : 1.0, info[(size_t)b]);
+    if (quad_h) quad_h[b] = quad[(size_t)b];
+    if (logdet_h) logdet_h[b] = ld[(size_t)b];
+    if (info_h) info_h[b] = info[(size_t)b];
+  }
+  return SMN_OK;
+}
+
+extern "C" int smn_spr_predict_batch(smn_ctx* ctx, int dtype, int net, int act, int num_hiddens, int nprob, const double* w_std,
+                                     const double* b_std, const double* last_w_std, const void* x_d, int64_t n, int64_t ldx,
+                                     const void* xt_d, int64_t t, int64_t ldxt, int64_t d, const void* y_d, int64_t c,
+                                     const double* ridge_rel, const double* ridge_abs, void* mean_d, void* cov_d, int64_t ldcov,
+                                     void* var_d, double* quad_h, double* logdet_h, int* info_h) {
+  if (!ctx || !x_d || !y_d || (t > 0 && !xt_d)) return SMN_EINVAL;
+  SMN_ENTER(ctx);
+  if (nprob <= 0 || !ridge_rel) return smn_fail(ctx, SMN_EINVAL, "smn_spr_predict_batch: empty batch or null ridge_rel");
+  std::vector<double> zero;
+  if (!ridge_abs) {
+    zero.assign((size_t)nprob, 0.0);
+    ridge_abs = zero.data();
+  }
+  return spr_batch(ctx, "smn_spr_predict_batch", dtype, net, act, num_hiddens, nprob, w_std, b_std, last_w_std, x_d, n, ldx, xt_d, t, ldxt,
+                   d, y_d, c, ridge_rel, ridge_abs, mean_d, cov_d, ldcov, var_d, quad_h, logdet_h, info_h);
 }
 
 extern "C" int smn_spr_predict(smn_ctx* ctx, int dtype, int net, int act, int num_hiddens, double w_std, double b_std,

@@ -53,6 +53,9 @@ struct BuildCall {
   int shard; int64_t shard_rb[2], shard_re[2]; void* shard_k[2]; void* shard_t[2]; int64_t shard_ld[2];
   // shard == 2: cyclic column-first shard (ColPieces below); shard_k[0] / shard_t[0] = the rank's chunk
   int cy_P, cy_rank, cy_np; int64_t cy_c[kMaxColPieces + 1]; int64_t cy_off[kMaxColPieces];
+  // batched build (nbatch > 0): the same operands under nbatch layer programs that differ in (w_std, b_std, last_w_std)
+  // only -- host arrays bw / bb / blw --, problem g written at out_k + g * out_bs elements
+  int nbatch; const double* bw; const double* bb; const double* blw; int64_t out_bs;
 };
 int run_build(smn_ctx* ctx, const BuildCall& c);
 

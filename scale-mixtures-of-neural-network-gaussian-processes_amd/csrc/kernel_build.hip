@@ -8,6 +8,8 @@
 //                      into the epilogue, so K0 never exists in HBM
 //   4. recursion_kernel: the same per-element program as an HBM-streaming pass over a stored K0
 //                      (hyper-parameter sweeps that reuse K0; the roofline measurement of a3)
+#include <vector>
+
 #include "gemm_nt.hpp"
 #include "internal.hpp"
 #include "layer_prog.hpp"
@@ -40,9 +42,14 @@ __global__ void pad_rows_kernel(const T* __restrict__ src, int64_t n, int64_t ld
 // closed-form NNGP / NTK diagonal (c = 1: ReLU Kdot = 1/2, erf Kdot = 4 / (pi sqrt(1 + 4q))).
 template <typename T>
 __global__ void diag_tables_kernel(const double* __restrict__ q0, int64_t n, LayerProg p,
-                                   T* __restrict__ tab, int64_t ldt, T* __restrict__ dg, T* __restrict__ dgt) {
+                                   T* __restrict__ tab, int64_t ldt, T* __restrict__ dg, T* __restrict__ dgt,
+                                   const LayerProg* __restrict__ progs = nullptr, int64_t tab_bs = 0) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  if (progs) {   // batched build: problem blockIdx.y has its own (w, b, last_w) and its own table block
+    p = progs[blockIdx.y];
+    tab += (int64_t)blockIdx.y * tab_bs; dg += (int64_t)blockIdx.y * tab_bs; dgt += (int64_t)blockIdx.y * tab_bs;
+  }
   double q = q0[i], th = 0.0;
   if (p.net == NET_RESNET) {
     q = p.w2 * q + p.b2;
@@ -111,6 +118,9 @@ struct BuildArgs {
   // [cy_c[g], cy_c[g+1]) of every tile row from cy_c[g] down, cy_c[g] a multiple of P): slot (j - cy_c[g]/P) of piece g is a
   // 128 x (width of the piece) strip.  sh_k[0] / sh_t[0] are the chunk bases.
   int cy_P, cy_rank, cy_T, cy_np; int cy_c[kMaxColPieces + 1]; int64_t cy_off[kMaxColPieces];
+  // batched build (smn_spr_loss_batch / smn_spr_predict_batch): problem blockIdx.y = the same operands under its own layer
+  // program progs[y] (same net, act and depth; its own w, b, last_w), its own table block and its own output matrix
+  const LayerProg* progs; int64_t tab_bs, out_bs; int nbatch;
 };
 
 // BM = 64 (sharded f32 builds of few tiles only): two workgroups per 128x128 tile, 64 rows each -- a piece of a pipelined shard is
@@ -200,8 +210,15 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 8 && NTK) ? 1 : (BM == 64 &
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
-  const ElemProg<T, NET, ACT, NTK> prog(a.prog);
+  ElemProg<T, NET, ACT, NTK> prog(a.prog);
   const int nsets = a.prog.nsets;
+  if (a.progs) {
+    prog = ElemProg<T, NET, ACT, NTK>(a.progs[blockIdx.y]);
+    const int64_t tb = (int64_t)blockIdx.y * a.tab_bs, ob = (int64_t)blockIdx.y * a.out_bs;
+    a.tab1 += tb; a.tab2 += tb; a.dg += tb; a.dgt += tb;
+    if (out_k) out_k += ob;
+    if (out_t) out_t += ob;
+  }
 
   // stage the per-row / per-column layer tables of this tile in LDS (mainloop ended on a barrier)
   constexpr bool FAST = ElemProg<T, NET, ACT, NTK>::FAST;
@@ -495,7 +512,7 @@ int launch_build_t(smn_ctx* ctx, const BuildArgs<T>& a, int64_t ntiles, size_t l
   SMN_TRY(smn_allow_lds(ctx, reinterpret_cast<const void*>(kern), lds));
   {
     ProfScope ps(ctx, PROF_BUILD, ctx->stream);
-    hipLaunchKernelGGL(kern, dim3((unsigned)ntiles), dim3(256), lds, ctx->stream, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)ntiles, (unsigned)(a.progs ? a.nbatch : 1)), dim3(256), lds, ctx->stream, a);
   }
   SMN_CHECK_LAUNCH(ctx);
   return SMN_OK;
@@ -537,16 +554,35 @@ int run_build_t(smn_ctx* ctx, const BuildCall& c) {
   const bool ntk = (c.get_mask & SMN_GET_NTK) != 0;
   if (ntk && prog.net == NET_NONE) return smn_fail(ctx, SMN_EINVAL, "NTK of a bare Gram");
   set_fast<T>(&prog, ntk);
-  // tables: [2*nsets + 2] rows of length rows1 (+ rows2 when not symmetric)
+  // tables: [2*nsets + 2] rows of length rows1 (+ rows2 when not symmetric); one such block per problem of a batched build
   const int trows = 2 * prog.nsets + 2;
   const int64_t tlen = c.symmetric ? c.rows1 : c.rows1 + c.rows2;
+  const int nb = c.nbatch > 0 ? c.nbatch : 1;
+  const int64_t tab_bs = (int64_t)trows * tlen;
   void* tabv = nullptr;
-  SMN_TRY(smn_workspace(ctx, 1, sizeof(T) * (size_t)trows * (size_t)tlen, &tabv));
+  SMN_TRY(smn_workspace(ctx, 1, sizeof(T) * (size_t)tab_bs * (size_t)nb, &tabv));
   T* tab1 = static_cast<T*>(tabv);
   T* dg1 = tab1 + (int64_t)(2 * prog.nsets) * tlen;
   T* dgt1 = dg1 + tlen;
-  hipLaunchKernelGGL(diag_tables_kernel<T>, dim3((unsigned)((c.rows1 + 255) / 256)), dim3(256), 0, ctx->stream,
-                     c.q1, c.rows1, prog, tab1, tlen, dg1, dgt1);
+  LayerProg* progs_d = nullptr;
+  if (c.nbatch > 0) {
+    if (!c.symmetric || c.shard) return smn_fail(ctx, SMN_EINVAL, "run_build: a batched build is symmetric and unsharded");
+    std::vector<LayerProg> hp((size_t)nb);
+    for (int g = 0; g < nb; ++g) {
+      BuildSpec sg = c.spec;
+      sg.w_std = c.bw[g]; sg.b_std = c.bb[g]; sg.last_w_std = c.blw[g];
+      SMN_TRY(make_prog(ctx, sg, &hp[(size_t)g]));
+      set_fast<T>(&hp[(size_t)g], ntk);
+    }
+    void* pv = nullptr;
+    SMN_TRY(smn_workspace(ctx, 6, sizeof(LayerProg) * (size_t)nb, &pv));
+    progs_d = static_cast<LayerProg*>(pv);
+    // (pageable source: the copy is staged before the call returns, so the vector may go)
+    SMN_HIP(ctx, hipMemcpyAsync(progs_d, hp.data(), sizeof(LayerProg) * (size_t)nb, hipMemcpyHostToDevice, ctx->stream));
+    SMN_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  hipLaunchKernelGGL(diag_tables_kernel<T>, dim3((unsigned)((c.rows1 + 255) / 256), (unsigned)nb), dim3(256), 0, ctx->stream,
+                     c.q1, c.rows1, prog, tab1, tlen, dg1, dgt1, progs_d, tab_bs);
   SMN_CHECK_LAUNCH(ctx);
   T* tab2 = tab1;
   if (!c.symmetric) {
@@ -563,6 +599,7 @@ int run_build_t(smn_ctx* ctx, const BuildCall& c) {
   a.lower_skip = (!c.symmetric && c.lower_skip) ? 1 : 0;
   a.tab1 = tab1; a.tab2 = tab2; a.ldt1 = tlen; a.ldt2 = tlen; a.dg = dg1; a.dgt = dgt1;
   a.inv_d = (T)(1.0 / (double)c.d); a.prog = prog;
+  a.progs = progs_d; a.tab_bs = tab_bs; a.out_bs = c.out_bs; a.nbatch = nb;
   a.row_off = c.row_off; a.col_off = c.col_off; a.exact_diag = c.exact_diag;
   a.store_mode = c.store_mode; a.out_rows = c.out_rows; a.out_cols = c.out_cols;
   a.nv0 = c.nv0; a.aug0 = c.aug0; a.nv1 = c.nv1;

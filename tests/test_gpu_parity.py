@@ -915,11 +915,74 @@ def test_find_grid_matches_reference_formulas():
                         tn = -np.mean(logsumexp(lps, axis=0))
                         assert abs(got["tnll"][i, j, k, ia, ib] - tn) < 1e-6 * max(1, abs(tn)), (w, b, eps, a, be)
     assert got["best_gaussian"] is not None and got["best_student"] is not None
-    # the same grid on three host threads / three contexts of the same GPU: identical tables
-    got3 = sweeps.find_grid(x, y, xt, yt, 0.2, 1.3, network="mlp", num_hiddens=2, activation="relu", w_std_list=ws,
-                            b_std_list=bs, eps_list=es, alpha_list=als, beta_list=bes, workers=3)
-    assert np.array_equal(got3["gnll"], got["gnll"]) and np.array_equal(got3["tnll"], got["tnll"])
-    assert got3["best_student"] == got["best_student"]
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("n,d,net,act,layers", [(245, 6, "mlp", "relu", 2), (700, 12, "mlp", "erf", 3), (1300, 20, "resnet", "relu", 2),
+                                                 (2048, 8, "mlp", "relu", 4)])
+def test_batched_loss_and_predict_are_bit_identical_to_the_serial_calls(L, ctx, dtype, n, d, net, act, layers):
+    """smn_spr_loss_batch / smn_spr_predict_batch: G problems of one data set under their own (w_std, b_std, last_w_std,
+    shift) in one sequence of launches (grid.y = G).  Every problem must reproduce the serial smn_spr_loss /
+    smn_spr_predict call BIT FOR BIT (same kernels, same tiles, same order), also when the batch runs in chunks, and the
+    oracle to tolerance; a problem that is not positive definite reports its own info and leaves the others alone."""
+    from smnngp import sweeps
+    rng = np.random.default_rng(500 + n)
+    xh = rng.standard_normal((n, d)).astype(dtype)
+    xh[7] = xh[3]                                              # two equal rows: singular without a shift
+    yh = rng.standard_normal((n, 1)).astype(dtype)
+    t = 37
+    xth = rng.standard_normal((t, d)).astype(dtype)
+    x, y, xt = ctx.to_device(xh), ctx.to_device(yh), ctx.to_device(xth)
+    code = L.dtype_code(dtype)
+    netc = L.NET_MLP if net == "mlp" else L.NET_DENSE_RESNET
+    ws = np.array([1.0, 1.4, 2.0, 0.7, 1.0, 1.2, 1.0])
+    bs = np.array([0.0, 0.3, 1.0, 0.1, 1e-8, 0.5, 0.2])
+    lws = np.array([1.0, 1.0, 0.5, 2.0, 1.0, 1.0, 1.0])
+    eps = np.array([1e-2, 1e-1, 1e-3, 1e-2, 1e-2, 3e-2, -50.0])  # the last one: a negative shift -> not positive definite
+    dfs = np.array([0.0, 4.0, 0.0, 2.0, 6.0, 0.0, 0.0])
+    scs = np.array([1.0, 1.5, 1.0, 0.5, 2.0, 1.0, 1.0])
+    g = len(ws)
+    lp, quad, logdet, info = C.c_double(), C.c_double(), C.c_double(), C.c_int()
+    want = []
+    for b in range(g):
+        ctx.call("smn_spr_loss", code, netc, L.ACT[act], layers, ws[b], bs[b], lws[b], x.ptr, n, d, d, y.ptr, eps[b], dfs[b], scs[b],
+                 C.byref(lp), C.byref(quad), C.byref(logdet), C.byref(info))
+        want.append((lp.value, quad.value, logdet.value, info.value))
+    assert want[-1][3] > 0 and all(w[3] == 0 for w in want[:-1])
+    for budget in (1 << 40, 3 * (n + 256) ** 2 * np.dtype(dtype).itemsize):      # one pass; chunks of at most three problems
+        ctx.call("smn_debug_batch_bytes", int(budget))
+        got = sweeps.loss_batch(ctx, x, y, network=net, num_hiddens=layers, activation=act, w_std=ws, b_std=bs, last_w_std=lws,
+                                eps=eps, df=dfs, scale=scs)
+        for b in range(g):
+            if want[b][3]:
+                assert got[3][b] == want[b][3] and np.isnan(got[0][b]) and np.isnan(got[2][b])
+            else:
+                assert (got[0][b], got[1][b], got[2][b], got[3][b]) == want[b], (b, budget)
+    ofn = O.mlp_kernel if net == "mlp" else O.dense_resnet_kernel
+    x64, y64 = xh.astype(np.float64), yh.astype(np.float64).ravel()
+    for b in (0, 1, 3):
+        kdd = ofn(x64, None, layers, act, ws[b], bs[b], lws[b]) + eps[b] * np.eye(n)
+        ref = O.mvn_logpdf(y64, kdd) if dfs[b] == 0 else O.mvt_logpdf(y64, scs[b] * kdd, dfs[b])
+        assert abs(want[b][0] - ref) < (1e-2 if dtype == np.float32 else 1e-7) * abs(ref)
+    # predict: relative ridge, mean / covariance / variance per problem
+    rel = np.array([1e-2, 1e-1, 1e-3, 1e-2, 1e-2, 3e-2, 1e-2])
+    mean_d, cov_d = ctx.empty((t, 1), dtype), ctx.empty((t, t), dtype)
+    wantp = []
+    for b in range(g):
+        ctx.call("smn_spr_predict", code, netc, L.ACT[act], layers, ws[b], bs[b], lws[b], x.ptr, n, d, xt.ptr, t, d, d, y.ptr, 1,
+                 rel[b], 0.0, mean_d.ptr, cov_d.ptr, t, None, None, C.byref(info))
+        assert info.value == 0
+        wantp.append((mean_d.numpy().copy(), cov_d.numpy().copy()))
+    for budget in (1 << 40, 2 * (n + 256) ** 2 * np.dtype(dtype).itemsize):
+        ctx.call("smn_debug_batch_bytes", int(budget))
+        kw = dict(network=net, num_hiddens=layers, activation=act, w_std=ws, b_std=bs, last_w_std=lws, diag_reg=rel)
+        mean, var, infop = sweeps.predict_batch(ctx, x, y, xt, **kw)
+        mean2, cov, _ = sweeps.predict_batch(ctx, x, y, xt, full_cov=True, **kw)
+        assert not infop.any() and np.array_equal(mean, mean2)
+        for b in range(g):
+            assert np.array_equal(mean[b], wantp[b][0]) and np.array_equal(cov[b], wantp[b][1])
+            assert np.array_equal(var[b], np.diag(wantp[b][1]))
+    ctx.call("smn_debug_batch_bytes", 48 << 30)
 
 
 def test_finite_difference_train_step():
