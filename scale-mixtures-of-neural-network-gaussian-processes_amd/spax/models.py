@@ -38,6 +38,27 @@ class SPR(Module):
             self._y64 = ctx.to_device(self.y_host)
         return self._x64, self._y64
 
+    def _student_quad_f64(self, kernel_fn, scale):
+        """y^T (K + (1e-6 / scale) I)^-1 y / scale  =  y^T (scale K + 1e-6 I)^-1 y in fp64 (likelihoods.py:60-61).
+        It depends on the training data and the hyper-parameters only -- not on the test points -- and the reference's
+        evaluation loop calls test_nll twice per check point, on the validation and on the test split
+        (experiments/regression/train.py:203-212, test.py:89-99): the value of the last parameter setting is kept, so the
+        second call costs the fp32 posterior alone.  (Measured at N = 16384: this fp64 build + factorisation is 44 ms
+        against 29 ms for the posterior, and running the two concurrently on two contexts buys 3 % -- both are bound by the
+        matrix pipes, not by latency; profiles/r04_two_context_probe.txt.)"""
+        key = (tuple(kernel_fn.params), float(scale))
+        hit = getattr(self, "_quad64_cache", None)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        xd, yd = self._f64_data()
+        net, act, L, w, b, lw = kernel_fn.params
+        quad, info = C.c_double(), C.c_int()
+        xd.ctx.call("smn_spr_loss", xd.dcode, net, act, L, w, b, lw, xd.ptr, xd.shape[0], xd.shape[1],
+                    xd.shape[1], yd.ptr, 1e-6 / scale, 0.0, 1.0, None, C.byref(quad), None, C.byref(info))
+        val = float("nan") if info.value else quad.value / scale
+        self._quad64_cache = (key, val)
+        return val
+
     # ---- spax/models.py:93-98
     def loss(self):
         eps = self.eps.safe_value
@@ -120,15 +141,7 @@ class SPR(Module):
                     # That matrix carries only a 1e-6 jitter: in fp32 it is not numerically PD (the
                     # reference's fp32 inv() returns noise there), so this one quadratic form always runs
                     # in fp64 on upcast copies of the training data.
-                    _, scale = self.likelihood.lml_params()
-                    xd, yd = self._f64_data()
-                    ctx = xd.ctx
-                    net, act, L, w, b, lw = kernel_fn.params
-                    quad, info = C.c_double(), C.c_int()
-                    ctx.call("smn_spr_loss", xd.dcode, net, act, L, w, b, lw, xd.ptr, xd.shape[0], xd.shape[1],
-                             xd.shape[1], yd.ptr, 1e-6 / scale, 0.0, 1.0, None, C.byref(quad), None,
-                             C.byref(info))
-                    cov_data = float("nan") if info.value else quad.value / scale
+                    cov_data = self._student_quad_f64(kernel_fn, self.likelihood.lml_params()[1])
                 else:
                     cov_data = self.kernel.K(kernel_fn, self._f64_data()[0])   # fp64 for the same reason
             aux_dict = dict(cov_data=cov_data, y_data=self.y_host)

@@ -225,6 +225,41 @@ def test_c2_gp_regression_against_the_oracle():
     assert relerr_norm(np.diagonal(np.asarray(cov)), np.diagonal(rcov)) < 1e-2
 
 
+def test_c2_student_t_test_nll_and_the_kept_quadratic_form():
+    """SPR.test_nll with the Student-t likelihood at N = 4096 against the oracle; the fp64 quadratic form
+    y^T (b/a K + 1e-6 I)^-1 y is kept for the last hyper-parameter setting (validation + test split of one check point:
+    train.py:203-212) and recomputed as soon as a hyper-parameter moves."""
+    from smnngp import nt_kernels
+    from smnngp.spax.kernels import NNGPKernel
+    from smnngp.spax.likelihoods import StudentTLikelihood
+    from smnngp.spax.models import SPR
+    n, t, d = 4096, 64, 512
+    rng = np.random.default_rng(4)
+    x = rng.standard_normal((n, d)).astype(np.float32); xt = rng.standard_normal((t, d)).astype(np.float32)
+    w = rng.standard_normal(d) / np.sqrt(d)
+    y = (np.tanh(x @ w) + 0.1 * rng.standard_normal(n)).astype(np.float32); yt = np.tanh(xt @ w).astype(np.float32)
+    kernel = NNGPKernel(lambda ws, bs, ls: nt_kernels.get_mlp_kernel(3, 1, act="relu", w_std=ws, b_std=bs, last_w_std=ls),
+                        1.2, 0.2, 1.0)
+    lik = StudentTLikelihood(2.0, 3.0)
+    model = SPR(kernel, lik, x, y, 0.1, 1.3, eps=1e-2)
+    first = model.test_nll(xt, yt)
+    key = model._quad64_cache[0]
+    assert model.test_nll(xt, yt) == first and model._quad64_cache[0] == key       # kept: same parameters
+    okw = dict(kernel="mlp", num_hiddens=3, act="relu", w_std=1.2, b_std=0.2, last_w_std=1.0, eps=1e-2, method="tp", alpha=2.0, beta=3.0)
+    x64, y64, xt64, yt64 = (a.astype(np.float64) for a in (x, y, xt, yt))
+    rn = O.spr_test_nll(x64, y64, xt64, yt64, 0.1, 1.3, **okw)
+    assert abs(first - rn) < 1e-2 * max(1.0, abs(rn))
+    kernel.w_std.assign(kernel.w_std.value + 0.05)                                  # a hyper-parameter moves: recomputed
+    second = model.test_nll(xt, yt)
+    assert model._quad64_cache[0] != key and second != first
+    okw["w_std"] = kernel.w_std.safe_value
+    rn2 = O.spr_test_nll(x64, y64, xt64, yt64, 0.1, 1.3, **okw)
+    assert abs(second - rn2) < 1e-2 * max(1.0, abs(rn2))
+    lik.b.assign(lik.b.value + 0.1)                                                 # ... and so does the likelihood's scale b/a
+    model.test_nll(xt, yt)
+    assert model._quad64_cache[0][1] != key[1]
+
+
 # ----------------------------------------------------------------------------- C5: N=32768 d=1024 L=6 erf NNGP+NTK fp32
 def test_c5_erf_nngp_and_ntk_sampled_parity_and_single_gpu_lml(L, ctx):
     n, d, nl = 32768, 1024, 6
