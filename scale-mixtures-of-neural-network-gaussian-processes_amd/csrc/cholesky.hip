@@ -925,6 +925,63 @@ __global__ void __launch_bounds__(256, 2) trail_kernel(UpdArgs<T> u, int ntiles)
   }
 }
 
+// out[i, j] = - sum_k x[i, k] x[j, k] for j <= i, where row i of x is zero left of column (i / 128) * 128 (x = L^-T as the
+// factorisation leaves it in the appended rows of an identity block): one workgroup per lower 128x128 tile, K from the tile
+// row's first column to kcols.  Tile rows are walked top down, so the longest K loops start first.
+template <typename T>
+__global__ void __launch_bounds__(256, 2) syrk_rows_kernel(const T* __restrict__ x, int64_t ldx, int64_t kcols, T* __restrict__ out,
+                                                          int64_t ldo, int64_t n) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using Tile = MainTile<T>;
+  using M = typename Tile::M;
+  int tr, tc;
+  tri_decode(blockIdx.x, tr, tc);
+  const int64_t row0 = (int64_t)tr * kTile, col0 = (int64_t)tc * kTile, k0 = row0;
+  Tile t;
+  t.zero();
+  t.mainloop(x + row0 * ldx + k0, ldx, x + col0 * ldx + k0, ldx, (int)(kcols - k0), smem);   // (run-time choice of the K loop: K = 128 ... kcols)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+#pragma unroll
+  for (int m = 0; m < Tile::MT; ++m)
+#pragma unroll
+    for (int nn = 0; nn < Tile::NT; ++nn)
+#pragma unroll
+      for (int i = 0; i < M::ACC; ++i) {
+        const int64_t gr = row0 + wr * Tile::WM + m * M::TM + M::acc_row(lane, i);
+        const int64_t gc = col0 + wc * Tile::WN + nn * M::TN + M::acc_col(lane);
+        if (gr < n && gc < n) out[gr * ldo + gc] = -t.acc[m][nn][i];
+      }
+}
+
+// alpha[i] = sum_k x[i, k] z[k] over k >= (i / 128) * 128 (one wave per row, fp64 accumulation); block 0 also leaves
+// quad = sum_k z[k]^2 (fixed order: reproducible).
+template <typename T>
+__global__ void __launch_bounds__(256) rows_dot_kernel(const T* __restrict__ x, int64_t ldx, const T* __restrict__ z, int64_t kcols,
+                                                       int64_t n, T* __restrict__ alpha, double* __restrict__ quad) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row < n) {
+    double s = 0.0;
+    for (int64_t k = row / kTile * kTile + lane; k < kcols; k += 64) s += (double)x[row * ldx + k] * (double)z[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) alpha[row] = (T)s;
+  }
+  if (blockIdx.x == 0) {
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int64_t k = threadIdx.x; k < kcols; k += 256) s += (double)z[k] * (double)z[k];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) *quad = red[0];
+  }
+}
+
 template <typename T>
 __global__ void diag_trace_kernel(const T* __restrict__ a, int64_t lda, int64_t n, double* __restrict__ out) {
   // single block; deterministic tree
@@ -1164,6 +1221,10 @@ int cholesky_t(smn_ctx* ctx, T* a, int64_t n_total, int64_t n_factor, int64_t ld
   if (Swide < S) Swide = S;
   hipStream_t sb = (n_total >= ctx->chain_min_n && ctx->stream_bulk) ? ctx->stream_bulk : nullptr;
   bool bulk_busy = false;
+  // ctx->chol_noschur: the trailing block of the appended rows (rows and columns >= n_factor) is neither read nor written
+  // -- the caller wants B L^-T only (grad.hip: X = L^-T from B = I, then K~^-1 = X X^T as one full-rate launch), and the
+  // matrix need not even have those columns (lda >= n_factor suffices)
+  const bool noschur = ctx->chol_noschur && n_factor < n_total;
   int rc = SMN_OK;
   auto hip_ok = [&](hipError_t e) {
     if (e != hipSuccess && rc == SMN_OK)
@@ -1222,7 +1283,8 @@ int cholesky_t(smn_ctx* ctx, T* a, int64_t n_total, int64_t n_factor, int64_t ld
       if (!sb) {   // far update, one launch
         SMN_TRY(need_columns(st, n_total));
         const int64_t tm = (n_total - s_end) / kTile;
-        SMN_TRY(launch_update<T>(ctx, st, a, lda, s_end, s_end, s0, K, tm, tm, 1));
+        if (!noschur) SMN_TRY(launch_update<T>(ctx, st, a, lda, s_end, s_end, s0, K, tm, tm, 1));
+        else if (n_factor > s_end) SMN_TRY(launch_update<T>(ctx, st, a, lda, s_end, s_end, s0, K, tm, (n_factor - s_end) / kTile, 2));
         continue;
       }
       const int64_t Sn = width(s_end);   // the next super-panel's width decides where F0 ends and F1 begins
@@ -1230,7 +1292,8 @@ int cholesky_t(smn_ctx* ctx, T* a, int64_t n_total, int64_t n_factor, int64_t ld
       // Once F1 is small (the chain-bound tail) it starts BEHIND F0 instead of beside it: F0 is on the chain's critical path
       // and, sharing the chip with an F1 that nobody waits for, takes three times as long (profiles/r02_tail_chain_timeline.txt).
       const int64_t tm1 = n_total > s_next ? (n_total - s_next) / kTile : 0;
-      const bool f0_first = tm1 * (tm1 + 1) / 2 <= kF0FirstTiles;
+      const int64_t tn1 = noschur ? (n_factor > s_next ? (n_factor - s_next) / kTile : 0) : tm1;   // F1's tile columns
+      const bool f0_first = tn1 * (tn1 + 1) / 2 + (tm1 - tn1) * tn1 <= kF0FirstTiles;
       if (!f0_first) {
         SMN_HIP(ctx, hipEventRecord(ctx->ev_a, st));
         SMN_HIP(ctx, hipStreamWaitEvent(sb, ctx->ev_a, 0));
@@ -1243,11 +1306,18 @@ int cholesky_t(smn_ctx* ctx, T* a, int64_t n_total, int64_t n_factor, int64_t ld
         SMN_HIP(ctx, hipEventRecord(ctx->ev_a, st));
         SMN_HIP(ctx, hipStreamWaitEvent(sb, ctx->ev_a, 0));
       }
-      if (n_total > s_next) {   // F1
+      if (n_total > s_next && tn1 > 0) {   // F1
         const int64_t tm = (n_total - s_next) / kTile;
         bulk_busy = true;       // set first: an error below must still join the bulk stream
         SMN_TRY(need_columns(sb, n_total));
-        SMN_TRY(launch_update<T>(ctx, sb, a, lda, s_next, s_next, s0, K, tm, tm, 1));
+        if (!noschur) {
+          SMN_TRY(launch_update<T>(ctx, sb, a, lda, s_next, s_next, s0, K, tm, tm, 1));
+        } else {
+          // no Schur block: the triangle of the columns left, then the rectangle of the appended rows under it (two
+          // launches, so that each takes the XCD patch order a trapezoid does not have)
+          SMN_TRY(launch_update<T>(ctx, sb, a, lda, s_next, s_next, s0, K, tn1, tn1, 1));
+          if (tm > tn1) SMN_TRY(launch_update<T>(ctx, sb, a, lda, s_next + tn1 * kTile, s_next, s0, K, tm - tn1, tn1, 0, 1));
+        }
         SMN_HIP(ctx, hipEventRecord(ctx->ev_b, sb));
       }
     }
@@ -1279,6 +1349,36 @@ int cholesky_t(smn_ctx* ctx, T* a, int64_t n_total, int64_t n_factor, int64_t ld
 }
 
 }  // namespace
+
+// K~^-1 and alpha from the appended rows of a no-Schur factorisation of [[K~], [I], [y^T]] (internal.hpp).
+int inverse_from_rows(smn_ctx* ctx, int dtype, const void* x, int64_t ldx, const void* z, int64_t kcols, int64_t n,
+                      void* neg_inv, int64_t ldo, void* alpha, double* quad_dev) {
+  const int64_t t = (n + kTile - 1) / kTile, ntiles = t * (t + 1) / 2;
+  if (dtype == SMN_F64) SMN_TRY(set_lds_attrs<double>(ctx)); else SMN_TRY(set_lds_attrs<float>(ctx));
+  {
+    ProfScope ps(ctx, PROF_TRAIL, ctx->stream);
+    ctx->prof_flops[PROF_TRAIL] += 2.0 * kTile * kTile * (double)kTile * (double)(t * (t + 1) * (t + 2) / 6);
+    if (dtype == SMN_F64) {
+      SMN_TRY(smn_allow_lds(ctx, reinterpret_cast<const void*>(syrk_rows_kernel<double>), MainTile<double>::LDS_BYTES));
+      hipLaunchKernelGGL(syrk_rows_kernel<double>, dim3((unsigned)ntiles), dim3(256), MainTile<double>::LDS_BYTES, ctx->stream,
+                         static_cast<const double*>(x), ldx, kcols, static_cast<double*>(neg_inv), ldo, n);
+    } else {
+      SMN_TRY(smn_allow_lds(ctx, reinterpret_cast<const void*>(syrk_rows_kernel<float>), MainTile<float>::LDS_BYTES));
+      hipLaunchKernelGGL(syrk_rows_kernel<float>, dim3((unsigned)ntiles), dim3(256), MainTile<float>::LDS_BYTES, ctx->stream,
+                         static_cast<const float*>(x), ldx, kcols, static_cast<float*>(neg_inv), ldo, n);
+    }
+  }
+  SMN_CHECK_LAUNCH(ctx);
+  const unsigned gb = (unsigned)((n + 3) / 4);
+  if (dtype == SMN_F64)
+    hipLaunchKernelGGL(rows_dot_kernel<double>, dim3(gb), dim3(256), 0, ctx->stream, static_cast<const double*>(x), ldx,
+                       static_cast<const double*>(z), kcols, n, static_cast<double*>(alpha), quad_dev);
+  else
+    hipLaunchKernelGGL(rows_dot_kernel<float>, dim3(gb), dim3(256), 0, ctx->stream, static_cast<const float*>(x), ldx,
+                       static_cast<const float*>(z), kcols, n, static_cast<float*>(alpha), quad_dev);
+  SMN_CHECK_LAUNCH(ctx);
+  return SMN_OK;
+}
 
 int cholesky_padded(smn_ctx* ctx, int dtype, void* a, int64_t n_total, int64_t n_factor, int64_t lda, int64_t n_shift,
                     double jitter_abs, double ridge_rel, bool keep_factor, int64_t id0, int64_t id1) {

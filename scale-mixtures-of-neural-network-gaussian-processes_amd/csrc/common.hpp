@@ -66,6 +66,7 @@ struct smn_ctx {
   // elements, its logdet / info in batch_logdet[g] / batch_info[g]; every panel / update launch gets grid.y = batch
   size_t batch_bytes = (size_t)48 << 30;   // workspace budget of one batched pass (smn_debug_batch_bytes)
   int batch = 1; int64_t batch_stride = 0, batch_ldiag_stride = 0; double* batch_logdet = nullptr; int* batch_info = nullptr;
+  bool chol_noschur = false;         // the factorisation in flight leaves the appended rows' trailing block alone (cholesky.hip)
   bool chol_prepped = false;         // the caller has shifted the diagonal and reset logdet / info already (aug_prep)
   std::unordered_map<const void*, size_t> max_lds;   // largest dynamic-LDS size already allowed per kernel (smn_allow_lds)
   bool lds_attrs_done[2] = {false, false};   // hipFuncSetAttribute(MaxDynamicSharedMemorySize) issued for f32 / f64 kernels

@@ -344,7 +344,8 @@ extern "C" int smn_lml_grad_terms(smn_ctx* ctx, int dtype, int net, int act, int
 }
 
 // Fused: K0 = X X^T / d and its diagonal, K by the stand-alone recursion straight into the factorisation workspace
-// laid out as [[K, .], [I, 0]], ONE augmented factorisation (alpha, -K~^-1, quad, logdet), then the contraction.
+// laid out as the rectangle [[K~], [I], [y^T]], a no-Schur factorisation (L, L^-T, L^-1 y), -K~^-1 = -L^-T L^-1 as one
+// full-rate launch, alpha = L^-T (L^-1 y) (heads.hip factor_with_identity), then the contraction.
 extern "C" int smn_spr_loss_grad(smn_ctx* ctx, int dtype, int net, int act, int num_hiddens, double w_std,
                                  double b_std, double last_w_std, const void* x_d, int64_t n, int64_t ldx, int64_t d,
                                  const void* y_d, double eps_abs, double df, double scale, double* quad_h,
@@ -363,7 +364,7 @@ extern "C" int smn_spr_loss_grad(smn_ctx* ctx, int dtype, int net, int act, int 
   void* q = static_cast<char*>(k0) + es * (size_t)n * ld0;
   void* ninv = post;
   void* alpha = static_cast<char*>(post) + es * (size_t)n * ld0;
-  SMN_TRY(smn_gram(ctx, dtype, x_d, n, ldx, nullptr, 0, 0, d, k0, ld0, q, nullptr));
+  SMN_TRY(gram_lower(ctx, dtype, x_d, n, ldx, d, k0, ld0, q));   // (lower tiles: all the recursion and the contraction read)
   double quad = 0.0, logdet = 0.0;
   int info = 0;
   SMN_TRY(factor_with_identity(ctx, dtype, net, act, num_hiddens, w_std, b_std, last_w_std, k0, ld0, q, n, y_d, eps_abs, alpha,

@@ -79,8 +79,7 @@ int aug_build(smn_ctx* ctx, const BuildSpec& spec, const Aug& g, const void* x, 
 }
 
 int aug_finish(smn_ctx* ctx, int dtype, const Aug& g, const void* y, int64_t ldy, int64_t n_shift, double jitter_abs,
-               double ridge_rel, void* mean, void* cov, int64_t ldcov, double* quad_h, double* logdet_h, int* info_h,
-               bool td_identity = false) {
+               double ridge_rel, void* mean, void* cov, int64_t ldcov, double* quad_h, double* logdet_h, int* info_h) {
   if (g.c > 48) return smn_fail(ctx, SMN_ENOTSUP, "more than 48 output columns");   // the mailbox holds 62 doubles
   // with an absolute jitter only, the right-hand-side rows, the diagonal shift and the scalar reset are one launch
   const bool prepped = ridge_rel == 0.0 && g.c > 0;
@@ -88,10 +87,8 @@ int aug_finish(smn_ctx* ctx, int dtype, const Aug& g, const void* y, int64_t ldy
     SMN_TRY(aug_prep(ctx, dtype, g.a, g.lda, g.n_pad + g.t, g.n_total, y, g.n, g.c, ldy, jitter_abs != 0.0 ? n_shift : 0, jitter_abs));
   else
     SMN_TRY(set_aug_rows(ctx, dtype, g.a, g.lda, g.n_pad + g.t, g.n_total, y, g.n, g.c, ldy));
-  // identity test rows: whole 128-row tiles of them may be skipped where they are structurally zero
-  const int64_t id0 = td_identity ? g.n_pad : -1, id1 = td_identity ? g.n_pad + g.t / kTile * kTile : -1;
   ctx->chol_prepped = prepped;
-  const int crc = cholesky_padded(ctx, dtype, g.a, g.n_total, g.n_pad, g.lda, n_shift, jitter_abs, ridge_rel, false, id0, id1);
+  const int crc = cholesky_padded(ctx, dtype, g.a, g.n_total, g.n_pad, g.lda, n_shift, jitter_abs, ridge_rel, false);
   ctx->chol_prepped = false;
   SMN_TRY(crc);
   double* quad_dev = ctx->d_scal + 8;
@@ -447,32 +444,60 @@ __global__ void identity_block_kernel(T* __restrict__ a, int64_t lda, int64_t n)
 
 }  // namespace
 
-// Analytic gradients (grad.hip): smn_predict's factorisation with K_td = I, K_tt = 0, the joint matrix assembled IN the
-// factorisation workspace -- the layer recursion of the Gram matrix k0 writes K there -- instead of being copied into it
-// from a second 2N x 2N matrix.  alpha = K~^-1 y comes back as the "mean", -K~^-1 as the "covariance".
+// Analytic gradients (grad.hip): alpha = K~^-1 y and -K~^-1 without a 2N x 2N matrix.  The workspace is the RECTANGLE
+//        [ K~ ]   n_pad rows        (K by the layer recursion of the Gram matrix k0, straight into it)
+//   A =  [ I  ]   n rows            identity block: row i is structurally zero left of column i
+//        [ y^T]   1 row (+ padding)
+// of n_pad columns.  A no-Schur factorisation (cholesky.hip: the appended rows' trailing block is never touched, and here
+// does not exist) leaves L, X = I L^-T = L^-T (upper triangular rows) and z^T = (L^-1 y)^T; then ONE full-rate launch forms
+// -K~^-1 = -X X^T (each tile's K loop starts at its row's first non-zero column) straight into the caller's matrix, and a
+// row pass gives alpha = X z and the quadratic form z^T z.  Same N^3 flops as the joint factorisation of [[K~, .], [I, 0]]
+// (round 3), half its memory (2 N^2 instead of 4 N^2 elements), and the N^3 / 3 of the inverse no longer rides on the panel
+// chain.
 int factor_with_identity(smn_ctx* ctx, int dtype, int net, int act, int num_hiddens, double w_std, double b_std,
                          double last_w_std, const void* k0_d, int64_t ldk0, const void* q_d, int64_t n, const void* y_d,
                          double eps_abs, void* alpha_d, void* ninv_d, int64_t ldinv, double* quad_h, double* logdet_h,
                          int* info_h) {
-  Aug g;
-  SMN_TRY(aug_alloc(ctx, dtype, n, n, 1, &g));
-  SMN_HIP(ctx, hipMemsetAsync(g.at(n, 0), 0, g.es * (size_t)(g.n_total - n) * (size_t)g.lda, ctx->stream));
+  const size_t es = dtype_size(dtype);
+  const int64_t n_pad = round_up(n, kTile), n_app = round_up(n + 1, kTile), n_total = n_pad + n_app, lda = n_pad;
+  void* av = nullptr;
+  SMN_TRY(smn_workspace(ctx, 2, es * (size_t)n_total * (size_t)lda, &av));
+  char* a = static_cast<char*>(av);
+  SMN_HIP(ctx, hipMemsetAsync(a + es * (size_t)n * (size_t)lda, 0, es * (size_t)(n_total - n) * (size_t)lda, ctx->stream));
   SMN_TRY(smn_recursion(ctx, dtype, net, act, num_hiddens, w_std, b_std, last_w_std, k0_d, n, n, ldk0, q_d, q_d, 1,
-                        SMN_GET_NNGP, g.a, nullptr, g.lda));
+                        SMN_GET_NNGP, a, nullptr, lda));
+  char* xrows = a + es * (size_t)n_pad * (size_t)lda;
   if (dtype == SMN_F64)
     hipLaunchKernelGGL(identity_block_kernel<double>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
-                       reinterpret_cast<double*>(g.at(g.n_pad, 0)), g.lda, n);
+                       reinterpret_cast<double*>(xrows), lda, n);
   else
     hipLaunchKernelGGL(identity_block_kernel<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
-                       reinterpret_cast<float*>(g.at(g.n_pad, 0)), g.lda, n);
+                       reinterpret_cast<float*>(xrows), lda, n);
   SMN_CHECK_LAUNCH(ctx);
-  SMN_TRY(fill_identity_pad(ctx, dtype, g.a, g.lda, g.n_pad, n));
-  return aug_finish(ctx, dtype, g, y_d, 1, n, eps_abs, 0.0, alpha_d, ninv_d, ldinv, quad_h, logdet_h, info_h, true);
+  SMN_TRY(fill_identity_pad(ctx, dtype, a, lda, n_pad, n));
+  // y^T in the row behind the identity block, the absolute jitter on the diagonal, logdet / info reset: one launch
+  SMN_TRY(aug_prep(ctx, dtype, a, lda, n_pad + n, n_pad, y_d, n, 1, 1, eps_abs != 0.0 ? n : 0, eps_abs));
+  ctx->chol_prepped = true;
+  ctx->chol_noschur = true;
+  const int crc = cholesky_padded(ctx, dtype, a, n_total, n_pad, lda, n, eps_abs, 0.0, false, n_pad, n_pad + n / kTile * kTile);
+  ctx->chol_prepped = false;
+  ctx->chol_noschur = false;
+  SMN_TRY(crc);
+  double* quad_dev = ctx->d_scal + 8;
+  SMN_TRY(inverse_from_rows(ctx, dtype, xrows, lda, xrows + es * (size_t)n * (size_t)lda, n_pad, n, ninv_d, ldinv, alpha_d, quad_dev));
+  double ld = 0.0, quad = 0.0;
+  int info = 0;
+  SMN_TRY(fetch_results(ctx, quad_dev, 1, &quad, &ld, &info));
+  if (info != 0) ld = quad = std::nan("");
+  if (quad_h) *quad_h = quad;
+  if (logdet_h) *logdet_h = ld;
+  if (info_h) *info_h = info;
+  return SMN_OK;
 }
 
 int predict_joint(smn_ctx* ctx, int dtype, void* kj_d, int64_t n, int64_t t, int64_t ldk, const void* y_d, int64_t c,
                   double ridge_rel, double ridge_abs, void* mean_d, void* cov_d, int64_t ldcov, double* quad_h,
-                  double* logdet_h, int* info_h, bool td_identity) {
+                  double* logdet_h, int* info_h) {
   if (!ctx || !kj_d || !y_d) return SMN_EINVAL;
   if (dtype != SMN_F32 && dtype != SMN_F64) return smn_fail(ctx, SMN_EINVAL, "bad dtype");
   if (n <= 0 || t < 0 || c <= 0) return smn_fail(ctx, SMN_EINVAL, "smn_predict: bad sizes");
@@ -485,8 +510,7 @@ int predict_joint(smn_ctx* ctx, int dtype, void* kj_d, int64_t n, int64_t t, int
   SMN_TRY(copy_matrix(ctx, dtype, g.at(g.n_pad, 0), g.lda, kb + g.es * (size_t)(n * ldk), ldk, t, n, 0));
   SMN_TRY(copy_matrix(ctx, dtype, g.at(g.n_pad, g.n_pad), g.lda, kb + g.es * (size_t)(n * ldk + n), ldk, t, t, 1));
   SMN_TRY(fill_identity_pad(ctx, dtype, g.a, g.lda, g.n_pad, n));
-  return aug_finish(ctx, dtype, g, y_d, c, n, ridge_abs, ridge_rel, mean_d, cov_d, ldcov, quad_h, logdet_h, info_h,
-                    td_identity && t == n);
+  return aug_finish(ctx, dtype, g, y_d, c, n, ridge_abs, ridge_rel, mean_d, cov_d, ldcov, quad_h, logdet_h, info_h);
 }
 
 extern "C" int smn_predict(smn_ctx* ctx, int dtype, void* kj_d, int64_t n, int64_t t, int64_t ldk, const void* y_d,
@@ -495,7 +519,7 @@ extern "C" int smn_predict(smn_ctx* ctx, int dtype, void* kj_d, int64_t n, int64
   if (!ctx) return SMN_EINVAL;
   SMN_ENTER(ctx);
   return predict_joint(ctx, dtype, kj_d, n, t, ldk, y_d, c, ridge_rel, ridge_abs, mean_d, cov_d, ldcov, quad_h, logdet_h,
-                       info_h, false);
+                       info_h);
 }
 
 extern "C" int smn_spr_loss(smn_ctx* ctx, int dtype, int net, int act, int num_hiddens, double w_std, double b_std,

@@ -70,17 +70,21 @@ inline int64_t k_pad(int dtype, int64_t d) { return round_up(d, dtype == SMN_F64
 int cholesky_padded(smn_ctx* ctx, int dtype, void* a, int64_t n_total, int64_t n_factor, int64_t lda,
                     int64_t n_shift, double jitter_abs, double ridge_rel, bool keep_factor,
                     int64_t id0 = -1, int64_t id1 = -1);   // id0/id1: appended rows [id0, id1) are an identity block
-// smn_predict with a promise about K_td: td_identity = the test rows of kj_d are [I, 0] (t == n), which lets the
-// factorisation skip their structural zeros (analytic gradients: alpha and -K~^-1 from one factorisation)
 int predict_joint(smn_ctx* ctx, int dtype, void* kj_d, int64_t n, int64_t t, int64_t ldk, const void* y_d, int64_t c,
                   double ridge_rel, double ridge_abs, void* mean_d, void* cov_d, int64_t ldcov, double* quad_h,
-                  double* logdet_h, int* info_h, bool td_identity);
-// the same factorisation with K_td = I, K_tt = 0 assembled in place from the Gram matrix k0 (heads.hip; analytic gradients)
+                  double* logdet_h, int* info_h);
+// alpha = K~^-1 y and -K~^-1 for the analytic gradients: a no-Schur factorisation of the rectangle [[K~], [I], [y^T]] (K from
+// the Gram matrix k0 by the layer recursion, in place), then -L^-T L^-1 as one launch (heads.hip)
 int factor_with_identity(smn_ctx* ctx, int dtype, int net, int act, int num_hiddens, double w_std, double b_std,
                          double last_w_std, const void* k0_d, int64_t ldk0, const void* q_d, int64_t n, const void* y_d,
                          double eps_abs, void* alpha_d, void* ninv_d, int64_t ldinv, double* quad_h, double* logdet_h,
                          int* info_h);
 int fetch_logdet_info(smn_ctx* ctx, double* logdet, int* info);
+int gram_lower(smn_ctx* ctx, int dtype, const void* x_d, int64_t n, int64_t ldx, int64_t d, void* k0_d, int64_t ldk, void* q_d);
+// -x x^T (lower, into neg_inv [n, n] ld = ldo) and alpha = x z from the rows x [n, kcols] (ld = ldx, row i zero left of its
+// 128-column tile) and the vector z [kcols]; *quad_dev = z^T z.  cholesky.hip.
+int inverse_from_rows(smn_ctx* ctx, int dtype, const void* x, int64_t ldx, const void* z, int64_t kcols, int64_t n,
+                      void* neg_inv, int64_t ldo, void* alpha, double* quad_dev);
 // logdet, info and nq device doubles (quadratic forms) through the pinned mailbox: one tiny kernel + ONE synchronisation
 int fetch_results(smn_ctx* ctx, const double* quad_dev, int nq, double* quad_h, double* logdet, int* info);
 

@@ -972,6 +972,13 @@ extern "C" int smn_kernel_mlp_shard_cols(smn_ctx* ctx, int dtype, int net, int a
   return run_build(ctx, c);
 }
 
+// smn_gram of x with itself, lower 128x128 tiles only (diagonal tiles whole): what the symmetric recursion and the gradient
+// contraction read; saves the mirrored store of the full form.
+int gram_lower(smn_ctx* ctx, int dtype, const void* x_d, int64_t n, int64_t ldx, int64_t d, void* k0_d, int64_t ldk, void* q_d) {
+  BuildSpec s{dtype, NET_NONE, SMN_ACT_RELU, 0, 1.0, 0.0, 1.0};
+  return build_public(ctx, s, x_d, n, ldx, nullptr, 0, 0, d, SMN_GET_NNGP, SMN_FILL_LOWER, 0, 0, k0_d, nullptr, ldk, q_d, nullptr);
+}
+
 extern "C" int smn_gram(smn_ctx* ctx, int dtype, const void* x1_d, int64_t n1, int64_t ldx1, const void* x2_d,
                         int64_t n2, int64_t ldx2, int64_t d, void* k0_d, int64_t ldk, void* q1_d, void* q2_d) {
   SMN_TRY(check_common(ctx, dtype, n1, x2_d ? n2 : 1, d));
