@@ -66,11 +66,16 @@ __global__ void diag_tables_kernel(const double* __restrict__ q0, int64_t n, Lay
       sv = sqrt(qt / (2.0 * nngp::kPi));
       qa = 0.5 * qt;
       kdot = 0.5;
+      if (p.fast) sv = sqrt(0.5 * qt);   // the fast map returns J / pi: s_i s_j pi (J / pi) = (sqrt(pi) s_i)(sqrt(pi) s_j) (J / pi)
     } else {
       r = 1.0 / sqrt(1.0 + 2.0 * qt);
       sv = 0.0;
       qa = (2.0 / nngp::kPi) * asin(2.0 * qt / (1.0 + 2.0 * qt));
       kdot = 4.0 / (nngp::kPi * sqrt(1.0 + 4.0 * qt));
+      if (p.fast) {   // correlation space: c = 2 K~ r_i r_j = K~ r'_i r'_j, x = asin c, K_act = (2/pi) x = s^2 x
+        r *= sqrt(2.0);
+        sv = sqrt(2.0 / nngp::kPi);
+      }
     }
     if (p.fast) {   // correlation-space tables (layer_prog.hpp): u = w s_prev r, v = b r
       tab[(int64_t)(2 * s) * ldt + i] = (T)(s == 0 ? w * r : w * s_prev * r);
@@ -499,7 +504,7 @@ int make_prog(smn_ctx* ctx, const BuildSpec& s, LayerProg* p) {
 // The launched kernel template decides FAST at compile time (layer_prog.hpp); the tables must agree.
 template <typename T>
 void set_fast(LayerProg* p, bool ntk) {
-  p->fast = (sizeof(T) == 4 && p->net == NET_MLP && p->act == ACT_RELU && !ntk) ? 1 : 0;
+  p->fast = (sizeof(T) == 4 && p->net == NET_MLP && !ntk) ? 1 : 0;
 }
 
 template <typename T, int NET, int ACT, bool NTK, int BM = kTile>

@@ -12,12 +12,16 @@
 // runs in CORRELATION space, which folds each Dense into the table products:
 //     x_0 = K0;   c_l = clamp(x_l * (u^l_i u^l_j) + v^l_i v^l_j);   x_{l+1} = J(c_l);   K = x_L * (sigma_i sigma_j)
 //     u^0 = w r^0, v^l = b r^l, u^l = w s^{l-1} r^l (l >= 1), sigma = last_w s^{L-1},  r = 1/sqrt(q~), s = sqrt(q~/2pi)
+// (the code carries x / pi: J comes back divided by pi and s is sqrt(q~/2) -- one multiplication less per layer)
 // It is the same arithmetic (c_l is exactly the argument the generic map forms) with 5 ops less per layer
 // and a single-sqrt J (nngp_math.hpp).  The table slots hold (u, v) instead of (r, s) and sigma rides in
 // the NTK-diagonal slot; diag_tables_kernel writes whichever the flag asks for.
-// (Round 3 tried the same form for erf -- x_{l+1} = asin(c_l), u^0 = sqrt(2) w r^0, u^l = (2/sqrt(pi)) w r^l, v^l = sqrt(2) b r^l,
-// sigma = last_w sqrt(2/pi): 4 ops less per layer of ~24, no measurable gain (symmetric L = 6: 0.53 -> 0.55 ms) and, asin being
-// steep at |c| -> 1, 1e-4 disagreements with the generic path in f32.  Not kept.)
+// Erf (f32, MLP, NNGP only; round 4) takes the same form: x_{l+1} = asin(c_l) with the same table recipe on r' = sqrt(2) r
+// and the constant s = sqrt(2/pi) (u^0 = w r', u^l = w s r', v = b r', sigma = last_w s), and a one-branch asin
+// (nngp_math.hpp asin_fast): 21.2 -> 13 vector instructions per element and layer (profiles/r04_recursion_instruction_budget.txt).
+// Round 3 had tried the folding alone (4 instructions of ~24) and measured no gain; with the shorter asin the map-bound
+// depths do move (profiles/r04_recursion_table.txt).  asin is steep at |c| -> 1, so entries of near-duplicate rows differ
+// from the generic path by up to 1e-4 in f32 -- both are equally far from the fp64 value there.
 #pragma once
 #include "nngp_math.hpp"
 
@@ -33,7 +37,7 @@ struct LayerProg {  // plain-old-data kernel argument
 
 template <typename T, int NET, int ACT, bool NTK>
 struct ElemProg {
-  static constexpr bool FAST = sizeof(T) == 4 && NET == NET_MLP && ACT == ACT_RELU && !NTK;
+  static constexpr bool FAST = sizeof(T) == 4 && NET == NET_MLP && !NTK;   // ReLU and erf
   T w2, b2, lw2;
   int nsets;
   __device__ __forceinline__ explicit ElemProg(const LayerProg& p)
@@ -54,8 +58,8 @@ struct ElemProg {
   // rr / ss: products of the two per-row table entries of this set (r_i r_j, s_i s_j; FAST: u_i u_j, v_i v_j)
   __device__ __forceinline__ void step(int set, T& k, T& th, T rr, T ss) const {
     if constexpr (FAST) {
-      const float c = __builtin_amdgcn_fmed3f(fmaf(k, rr, ss), -1.0f, 1.0f);
-      k = nngp::relu_j_fast(c);
+      const float c = fmaf(k, rr, ss);   // (clamped where it matters: inside the maps)
+      k = ACT == ACT_RELU ? nngp::relu_j_fast(c) : nngp::asin_fast(c);
     } else if (NET == NET_MLP) {
       const T kt = fma(w2, k, b2);
       T tht = T(0);

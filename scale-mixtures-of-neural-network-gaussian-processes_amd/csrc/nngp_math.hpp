@@ -151,7 +151,7 @@ __device__ __forceinline__ ActOut<T> relu_map(T kt, T rr, T ss) {
   if constexpr (!WANT_DOT) {   // NNGP only: the single-sqrt forms of J
     ActOut<T> o;
     if constexpr (sizeof(T) == 8) o.k = ss * relu_j_f64(c);
-    else o.k = ss * relu_j_fast(c);
+    else o.k = ss * (3.14159265358979323846f * relu_j_fast(c));
     o.kdot = T(0);
     return o;
   }
@@ -171,17 +171,39 @@ __device__ __forceinline__ ActOut<T> relu_map(T kt, T rr, T ss) {
 // R is analytic on [0,1]; the degree-5 fit below (minimax-refined least squares) gives |J - exact| <=
 // 3.2e-7 over [-1,1] in f32 arithmetic (1.0e-7 relative to J's range pi; the last ulp of pi is 2.4e-7).
 // J is 1-Lipschitz-ish (J' = pi - acos c <= pi), so this error does not amplify through the layers.
+__device__ __forceinline__ float clamp01(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, 1.0f); }   // folds into the producer's clamp modifier
+// Returns J(c) / pi (the factor pi rides in the next layer's table product: diag_tables_kernel).  c is NOT clamped on entry: a
+// product that rounds to |c| = 1 + 1e-7 only has to keep the square root real, which the [0, 1] clamp of 1 - |c| does for free.
 __device__ __forceinline__ float relu_j_fast(float c) {
   const float a = fabsf(c);
-  const float d = 1.0f - a;
+  const float d = clamp01(1.0f - a);
   const float s = __builtin_amdgcn_sqrtf(d);
-  float r = -0.0005345707759261131f;
-  r = fmaf(r, a, 0.00260539585724473f);
-  r = fmaf(r, a, -0.007160552311688662f);
-  r = fmaf(r, a, 0.018685804679989815f);
-  r = fmaf(r, a, -0.07078703492879868f);
-  r = fmaf(r, a, 0.9999998807907104f);
-  return fmaf(d * s, r, 1.57079632679489662f * (c + a));
+  float r = -0.00017015916819218546f;
+  r = fmaf(r, a, 0.0008293232531286776f);
+  r = fmaf(r, a, -0.002279274631291628f);
+  r = fmaf(r, a, 0.005947876255959272f);
+  r = fmaf(r, a, -0.022532213479280472f);
+  r = fmaf(r, a, 0.31830984354019165f);
+  return fmaf(d * s, r, fmaxf(c, 0.0f));
+}
+
+// asin(c) for |c| <= 1, f32 NNGP-only erf fast path: ONE branch-free formula,
+//   asin|c| = pi/2 - sqrt(1 - |c|) P7(|c|),   P7 = a minimax fit of (pi/2 - asin a) / sqrt(1 - a) on [0, 1] with P7(0) = fl(pi/2)
+// (so asin(0) = 0 exactly and the odd extension is continuous): 11 vector instructions and one sqrt against 14 and a sqrt for
+// the split form above.  |error| <= 2.6e-7 absolute over [-1, 1] in f32 arithmetic (the rounding of the pi/2 - ... difference;
+// the fit itself is 5e-8), i.e. 1.6e-7 of the kernel's range after the 2/pi: the accuracy class of relu_j_fast below.
+__device__ __forceinline__ float asin_fast(float c) {
+  const float a = fabsf(c);
+  const float s = __builtin_amdgcn_sqrtf(clamp01(1.0f - a));   // (c arrives unclamped: see relu_j_fast)
+  float r = -0.0015507979551330209f;
+  r = fmaf(r, a, 0.007713252678513527f);
+  r = fmaf(r, a, -0.01858212612569332f);
+  r = fmaf(r, a, 0.031964052468538284f);
+  r = fmaf(r, a, -0.050575364381074905f);
+  r = fmaf(r, a, 0.08905214071273804f);
+  r = fmaf(r, a, -0.21460402011871338f);
+  r = fmaf(r, a, 1.5707963705062866f);
+  return copysignf(fmaf(-s, r, 1.5707963705062866f), c);
 }
 
 // Erf map.  rr = r_i r_j with r = 1/sqrt(1+2q).

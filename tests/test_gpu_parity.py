@@ -48,10 +48,14 @@ def test_symmetric_kernel_nngp_ntk(dtype, act, net, n, d, layers):
     assert relerr(k, rk) < RTOL[dtype]
     assert relerr(t, rt) < RTOL[dtype] * 5
     assert np.array_equal(k, k.T)                      # mirrored store is exact
-    # single get: the f32 ReLU MLP takes the correlation-space fast path when no NTK is asked for
-    # (layer_prog.hpp), so the two results agree to rounding, not bit for bit
+    # single get: the f32 MLP takes the correlation-space fast path when no NTK is asked for (layer_prog.hpp: single-sqrt
+    # J / one-branch asin, |error| <= 3e-7 of the map's range), so the two results agree to that, not bit for bit
     k2 = np.asarray(kfn(x, x, get="nngp"))
-    assert relerr(k2, rk) < RTOL[dtype] and relerr(k2, k) < (1e-12 if dtype == np.float64 else 1e-5)
+    assert relerr(k2, rk) < RTOL[dtype]
+    if dtype == np.float64:
+        assert relerr(k2, k) < 1e-12
+    else:
+        assert np.abs(k2 - k).max() < 1e-6 * np.abs(k).max() and relerr(k2, k) < 5e-4
     assert np.array_equal(k2, k2.T)
 
 
