@@ -40,7 +40,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32 MFMA (16x16x4 and 32x32x2 forms alike), dense
-PEAK_F64_MFMA_TFLOPS = 78.6    # datasheet; the v_mfma_f64_16x16x4_f64 microbench: profiles/r02_mfma_f64_peak.txt
+PEAK_F64_MFMA_TFLOPS = 78.6    # datasheet: one v_mfma_f64_16x16x4_f64 per 64 cycles per SIMD at 2.4 GHz
+# What a hand-written stream of independent MFMAs sustains on the whole chip (profiles/r04_mfma_forms.txt: accumulators in VGPRs
+# or AGPRs alike, 1-4 waves per SIMD, clock 2.39 GHz): the datasheet figures are the hardware's rate.  (Round 3's "104 cycles per
+# f64 MFMA" was the compiler copying the accumulators VGPR <-> AGPR every iteration of the microbench's loop.)
+MEASURED_ISSUE_CEILING_TFLOPS = {"f32": 155.0, "f64": 77.4}
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s achievable)
 TILE = 128
 
@@ -576,6 +580,8 @@ def measure_mlp_loss(L, ctx, n, d, nl, act, dtype, eps, steps, warmup):
         "roofline": {"kernel": "Cholesky trailing update (update_kernel / trail_kernel)", "bound": "mfma",
                      "achieved": fl[5] / (trail_ms * 1e-3) / 1e12 if trail_ms > 0 else None, "peak": peak, "unit": "TFLOP/s",
                      "frac": fl[5] / (trail_ms * 1e-3) / 1e12 / peak if trail_ms > 0 else None,
+                     "peak_source": "datasheet (%s MFMA, dense)" % dtype,
+                     "frac_vs_measured_issue_ceiling": fl[5] / (trail_ms * 1e-3) / 1e12 / MEASURED_ISSUE_CEILING_TFLOPS[dtype] if trail_ms > 0 else None,
                      "launches_per_step": trail_cnt, "summed_launch_ms": trail_ms,
                      "cholesky_wall_ms": chol_wall,
                      "cholesky_mfma_frac": (fl[4] + fl[5]) / (chol_wall * 1e-3) / 1e12 / peak},
@@ -978,6 +984,10 @@ def main():
             "achieved": trail_fl / (trail_ms * 1e-3) / 1e12 if trail_ms > 0 else None,
             "peak": peak, "unit": "TFLOP/s",
             "frac": (trail_fl / (trail_ms * 1e-3) / 1e12 / peak) if trail_ms > 0 else None,
+            "peak_source": "datasheet (%s MFMA, dense): %.1f TFLOP/s" % (args.dtype, peak),
+            "frac_vs_measured_issue_ceiling": (trail_fl / (trail_ms * 1e-3) / 1e12 / MEASURED_ISSUE_CEILING_TFLOPS[args.dtype]) if trail_ms > 0 else None,
+            "measured_issue_ceiling": "%.1f TFLOP/s: independent v_mfma_%s_16x16x4 chains, whole chip (profiles/r04_mfma_forms.txt)"
+                                      % (MEASURED_ISSUE_CEILING_TFLOPS[args.dtype], args.dtype),
             # fabric-side bytes per launch cannot be read without rocprofv3: taken from the committed PMC pass of this exact
             # workload, else null
             "traffic": pmc_traffic(args, sharded)[0], "traffic_source": pmc_traffic(args, sharded)[1],
@@ -1110,8 +1120,12 @@ def main():
                 rec_traffic = None
                 if (args.n, args.layers, args.act, args.dtype) == (16384, 4, "relu", "f32"):
                     try:
-                        with open(os.path.join(ROOT, "profiles", "r01e_pmc_recursion.json")) as f:
-                            rec_traffic = json.load(f)["traffic_bytes_per_launch"]
+                        for name in ("r04_pmc_recursion.json", "r01e_pmc_recursion.json"):
+                            fn = os.path.join(ROOT, "profiles", name)
+                            if os.path.exists(fn):
+                                with open(fn) as f:
+                                    rec_traffic = json.load(f)["traffic_bytes_per_launch"]
+                                break
                     except Exception:
                         rec_traffic = None
                 # achieved = SURVEY 8(d) algorithmic bytes (read N^2 + write N^2) / time; the symmetric kernel reads

@@ -74,7 +74,18 @@ def build(force=False, verbose=False, variant="", defines=()):
     return lib
 
 
+def compiler_version():
+    """First line of `hipcc --version`: the leaf of the panel kernel is inline asm with hand-placed wait states, validated
+    against the instructions THIS compiler emits around it (tested: HIP 7.2 / AMD clang 22.0.0git roc-7.2.0)."""
+    try:
+        out = subprocess.run([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--version"], capture_output=True, text=True).stdout
+        return next((ln.strip() for ln in out.splitlines() if "clang version" in ln or "HIP version" in ln), out.strip()[:80])
+    except OSError as e:
+        return "hipcc not found (%s)" % e
+
+
 if __name__ == "__main__":
+    print("compiler:", compiler_version())
     argv = sys.argv[1:]
     variant = ""
     if "--variant" in argv:

@@ -118,6 +118,18 @@ def test_plateau_schedule_follows_the_reference_semantics():
         PlateauSchedule(0.1, threshold_mode="pct")
 
 
+def test_generated_panel_leaf_include_matches_its_generator():
+    """csrc/panel_leaf_steps.inc is inline asm with hand-placed wait states: the committed file must be exactly
+    what gen_panel_leaf.py writes, so an edit of one without the other cannot ship."""
+    import importlib.util
+    csrc = os.path.join(ROOT, "scale-mixtures-of-neural-network-gaussian-processes_amd", "csrc")
+    spec = importlib.util.spec_from_file_location("gen_panel_leaf", os.path.join(csrc, "gen_panel_leaf.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    with open(os.path.join(csrc, "panel_leaf_steps.inc")) as f:
+        assert f.read() == mod.render()
+
+
 def test_clean_tree_build_from_scratch(tmp_path):
     """`build()` is mtime-incremental and the built objects travel in the working tree, so the everyday build check can
     pass on stale objects.  This one compiles EVERY source from scratch (force=True, a variant directory of its own, removed
