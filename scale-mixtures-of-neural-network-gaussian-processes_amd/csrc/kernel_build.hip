@@ -217,10 +217,12 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 8 && NTK) ? 1 : (BM == 64 &
   const int wr = wave >> 1, wc = wave & 1;
   ElemProg<T, NET, ACT, NTK> prog(a.prog);
   const int nsets = a.prog.nsets;
+  // (locals, not writes into `a`: a kernel argument that is written gets a private copy in scratch)
+  const T* tab1 = a.tab1; const T* tab2 = a.tab2; const T* dgp = a.dg; const T* dgtp = a.dgt;
   if (a.progs) {
     prog = ElemProg<T, NET, ACT, NTK>(a.progs[blockIdx.y]);
     const int64_t tb = (int64_t)blockIdx.y * a.tab_bs, ob = (int64_t)blockIdx.y * a.out_bs;
-    a.tab1 += tb; a.tab2 += tb; a.dg += tb; a.dgt += tb;
+    tab1 += tb; tab2 += tb; dgp += tb; dgtp += tb;
     if (out_k) out_k += ob;
     if (out_t) out_t += ob;
   }
@@ -233,8 +235,8 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 8 && NTK) ? 1 : (BM == 64 &
   for (int idx = tid; idx < trows * kTile; idx += 256) {
     const int s2 = idx / kTile, r = idx % kTile;
     const int g2 = s2 < nsets * 2 ? s2 : nsets * 2 + 1;
-    if (r < BM) srow[idx] = a.tab1[(int64_t)g2 * a.ldt1 + row0 + r];
-    scol[idx] = a.tab2[(int64_t)g2 * a.ldt2 + col0 + r];
+    if (r < BM) srow[idx] = tab1[(int64_t)g2 * a.ldt1 + row0 + r];
+    scol[idx] = tab2[(int64_t)g2 * a.ldt2 + col0 + r];
   }
   __syncthreads();
 
@@ -293,8 +295,8 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 8 && NTK) ? 1 : (BM == 64 &
           sig = srow[nsets * 2 * kTile + (int)(gr - row0)] * scol[nsets * 2 * kTile + (int)(gc - col0)];
         prog.post(k, h, sig);
         if (a.exact_diag && gr + a.row_off == gc + a.col_off) {
-          k = a.dg[gr];
-          if (NTK) h = a.dgt[gr];
+          k = dgp[gr];
+          if (NTK) h = dgtp[gr];
         }
         bool wr_ok;
         if (a.store_mode == STORE_PAD_IDENTITY) {

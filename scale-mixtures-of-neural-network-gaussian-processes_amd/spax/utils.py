@@ -25,6 +25,8 @@ def factor_stats(x, cov):
     triangular_solve of spax/utils.py:179-180 and the Cholesky inside jax's MVN logpdf."""
     if not isinstance(cov, DeviceArray):
         cov = as_device(np.asarray(cov))
+    if not cov.scale > 0.0:      # the lazy form factors A + (shift / scale) I: only for a positive scale; anything else is
+        cov = as_device(cov)     # materialised as it stands (as_device resolves the view through the host)
     ctx = cov.ctx
     n = cov.shape[0]
     xv = as_device(np.asarray(x).reshape(-1), ctx, dtype=cov.dtype)

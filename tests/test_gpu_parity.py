@@ -870,17 +870,25 @@ def test_spr_loss_and_test_nll(dtype, method, network):
     assert abs(model2.test_nll(xte.astype(dtype), yte.astype(dtype)) - rn) < tol_nll * max(1.0, abs(rn))
 
 
-def test_not_pd_gives_nan_like_the_reference():
-    """JAX's Cholesky returns NaN on a non-PD matrix and the driver notices later (train.py:211)."""
+def test_not_pd_gives_nan_like_the_reference(L, ctx):
+    """JAX's Cholesky returns NaN on a non-PD matrix and the driver notices later (train.py:211): no exception, NaN out,
+    through the fused call (info = first bad pivot), the facade's likelihood on a device matrix, and the batched call."""
     from smnngp import nt_kernels
     from smnngp.spax.kernels import NNGPKernel
-    from smnngp.spax.likelihoods import GaussianLikelihood
-    from smnngp.spax.models import SPR
-    x = np.ones((40, 3))                                   # rank-1 kernel, eps tiny -> not PD in fp32
-    y = np.linspace(-1, 1, 40)
+    from smnngp.spax.likelihoods import GaussianLikelihood, StudentTLikelihood
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((40, 3)).astype(np.float32)
+    y = np.linspace(-1, 1, 40).astype(np.float32)
     k = NNGPKernel(lambda w, b, l: nt_kernels.get_mlp_kernel(1, act="relu", w_std=w, b_std=b, last_w_std=l), 1., 1e-8, 1.)
-    m = SPR(k, GaussianLikelihood(), x.astype(np.float32), y.astype(np.float32), 0.0, 1.0, eps=1e-12)
-    assert np.isnan(m.loss())
+    kmat = k.K(k.get_kernel_fn(), L.as_device(x, ctx))
+    neg = (-1.0) * kmat + L.ScaledIdentity(40, 1e-3)        # negative definite: the first pivot already fails
+    assert np.isnan(GaussianLikelihood().prior_logpdf(y, neg))
+    assert np.isnan(StudentTLikelihood(2.0, 2.0).prior_logpdf(y, neg))
+    xd, yd = ctx.to_device(x), ctx.to_device(y)
+    lp, info = C.c_double(), C.c_int()
+    ctx.call("smn_spr_loss", L.F32, L.NET_MLP, L.ACT["relu"], 1, 1.0, 1e-8, 1.0, xd.ptr, 40, 3, 3, yd.ptr, -5.0, 0.0, 1.0,
+             C.byref(lp), None, None, C.byref(info))         # K - 5 I: not positive definite
+    assert info.value >= 1 and np.isnan(lp.value)
 
 
 # ----------------------------------------------------------------------------- "next" rows (SURVEY 8f)
