@@ -1439,7 +1439,8 @@ def test_column_first_route_on_a_one_rank_communicator(L, ctx):
     tk = c2.to_device(np.full((n, n), np.nan, np.float32))
     got = S.lml_sharded_cols(S.DeviceBackend(c2), L.F32, spec, x2.ptr, n, d, d, y2.ptr, 0, 1, mine.ptr, stage.ptr,
                              1e-2, cols=cols, ntk=(mine_t.ptr, stage_t.ptr, tk.ptr, n))
-    assert got[3] == 0 and got[0] == lp.value
+    # (the joint NNGP + NTK build takes the generic maps, the NNGP-only smn_spr_loss above the f32 fast ones: rounding apart)
+    assert got[3] == 0 and abs(got[0] - lp.value) < 1e-5 * abs(lp.value)
     ref = ctx.empty((n, n), np.float32); ref_t = ctx.empty((n, n), np.float32)
     ctx.call("smn_kernel_mlp", L.F32, *spec, x.ptr, n, d, None, 0, 0, d, L.GET_NNGP | L.GET_NTK, L.FILL_LOWER, ref.ptr, ref_t.ptr, n)
     rr, cc = np.indices((n, n))
