@@ -1232,7 +1232,7 @@ int cholesky_t(smn_ctx* ctx, T* a, int64_t n_total, int64_t n_factor, int64_t ld
   };
   // Column-first multi-GPU exchange (heads.hip smn_lml_from_shards): the kernel's columns land in this workspace piece by
   // piece while the factorisation is already being issued.  A stream about to touch columns [.., col_hi) waits for the
-  // pieces that hold them, once each: the panel chain of a super-panel for its own columns, F0 for the next super-panel's,
+  // pieces that hold them, once each: a sub-panel for its own 128 columns, the near updates for their super-panel's, F0 for the next super-panel's,
   // the bulk update F1 for everything.  The first wait (super-panel 0) is what of the exchange is exposed; later ones are
   // stalls the first panel chain did not cover (separate profile categories).
   const bool arriving = ctx->consume_arrivals && !ctx->arrivals.empty();
@@ -1266,15 +1266,16 @@ int cholesky_t(smn_ctx* ctx, T* a, int64_t n_total, int64_t n_factor, int64_t ld
       const int64_t Sc = width(s0);
       const int64_t s_end = (n_factor - s0 < Sc) ? n_factor : s0 + Sc;
       s_stop = s_end;
-      SMN_TRY(need_columns(st, s_end));
       for (int64_t j0 = s0; j0 < s_end; j0 += W) {
         const int64_t w = (s_end - j0 < W) ? s_end - j0 : W;
         for (int64_t js = j0; js < j0 + w; js += PB) {
+          SMN_TRY(need_columns(st, js + PB));   // (arrivals: a sub-panel and its strip touch their own 128 columns only)
           if (js > j0)   // strip: the second sub-panel's 128 columns, K = 128
             SMN_TRY(launch_update<T>(ctx, st, a, lda, js, js, j0, js - j0, (n_total - js) / kTile, 1, 0));
           SMN_TRY(launch_panel<T>(ctx, st, a, lda, js, n_total, 0));
         }
         const int64_t j1 = j0 + w;
+        if (j1 < s_end) SMN_TRY(need_columns(st, s_end));
         if (j1 < s_end)   // near update: columns [j1, s_end), all rows from the diagonal down
           SMN_TRY(launch_update<T>(ctx, st, a, lda, j1, j1, j0, w, (n_total - j1) / kTile, (s_end - j1) / kTile, 2));
       }

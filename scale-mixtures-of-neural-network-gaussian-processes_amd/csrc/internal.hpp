@@ -3,21 +3,22 @@
 #include "common.hpp"
 
 constexpr int kTile = 128;   // GEMM block edge; every padded dimension is a multiple of it
-constexpr int kMaxColPieces = 16;   // pieces of a column-first exchange
+constexpr int kMaxColPieces = 32;   // pieces of a column-first exchange
 
 // Cyclic column-first shard of the symmetric kernel build over P ranks (host side: sharding.py, same formulas).
 //   tile rows (128 rows) are dealt in boustrophedon order with period 2P: group j = tile rows [jP, (j+1)P), rank r owns
 //   t_j(r) = jP + (j even ? r : P-1-r)  -- tile row t holds t+1 lower tiles, and every pair of groups gives every rank the same
 //   number of them, so the build is balanced and EVERY aligned group of P tile rows holds exactly one tile row per rank;
-//   piece g = tile columns [c[g], c[g+1]) (c[g] a multiple of P) of every tile row from c[g] down: slots = ceil((T - c[g]) / P)
-//   strips of 128 x (c[g+1]-c[g])*128 elements per rank -- the same count on every rank, so ONE equal-count all-gather moves a
-//   whole column range of the lower triangle (the tile rows that start inside it carry their above-diagonal tiles as padding).
+//   piece g = tile columns [c[g], c[g+1]) of every tile row from the group of c[g] down (group f = floor(c[g] / P)): slots =
+//   ceil(T / P) - f strips of 128 x (c[g+1]-c[g])*128 elements per rank -- the same count on every rank, so ONE equal-count
+//   all-gather moves a whole column range of the lower triangle (tile rows that start inside or above it carry their
+//   above-diagonal tiles as padding: at most one strip per rank and piece when c[g] is not a multiple of P).
 struct ColPieces {
   int P = 1, np = 0;
   int64_t T = 0;                       // tile rows of the kernel: ceil(n / 128)
   int64_t c[kMaxColPieces + 1] = {};   // tile-column boundaries, c[0] = 0, c[np] = T
   int64_t off[kMaxColPieces + 1] = {}; // element offset of piece g in a rank's chunk; off[np] = elements per rank
-  int64_t slots(int g) const { return (T - c[g] + P - 1) / P; }
+  int64_t slots(int g) const { return (T + P - 1) / P - c[g] / P; }
   int64_t width(int g) const { return (c[g + 1] - c[g]) * kTile; }
   int64_t count(int g) const { return slots(g) * kTile * width(g); }
 };

@@ -933,9 +933,9 @@ int col_pieces_make(smn_ctx* ctx, int64_t n, int nranks, int npieces, const int6
   if (cp.c[0] != 0 || cp.c[npieces] != cp.T)
     return smn_fail(ctx, SMN_EINVAL, "column pieces must span the tile columns [0, %lld)", (long long)cp.T);
   for (int g = 0; g < npieces; ++g) {
-    if (cp.c[g + 1] <= cp.c[g] || cp.c[g] % nranks)
-      return smn_fail(ctx, SMN_EINVAL, "column piece %d = [%lld, %lld): boundaries must ascend in multiples of the %d ranks", g,
-                      (long long)cp.c[g], (long long)cp.c[g + 1], nranks);
+    if (cp.c[g + 1] <= cp.c[g])
+      return smn_fail(ctx, SMN_EINVAL, "column piece %d = [%lld, %lld): boundaries must ascend", g, (long long)cp.c[g],
+                      (long long)cp.c[g + 1]);
     cp.off[g + 1] = cp.off[g] + cp.count(g);
   }
   *out = cp;

@@ -135,11 +135,12 @@ def _check_communicator(ctx, world):
 # 128-row tile rows are dealt in boustrophedon order with period 2P -- group j = tile rows [jP, (j+1)P), rank r owns
 # t_j(r) = jP + (r if j is even else P-1-r) -- so that (i) tile row t holds t+1 lower tiles and every pair of groups gives
 # every rank the same number of them: the build is balanced; (ii) every aligned group of P tile rows holds exactly one tile
-# row per rank: a tile-column range [c0, c1) with c0 a multiple of P is ceil((T - c0)/P) strips of 128 x (c1-c0)*128
-# elements on EVERY rank, one equal-count all-gather.  (Tile rows that start inside the range carry their above-diagonal
-# tiles as padding: 5.8 % of the bytes at N = 16384, P = 8.)  Mirrors csrc/internal.hpp ColPieces.
+# row per rank: a tile-column range [c0, c1) is ceil(T/P) - floor(c0/P) strips of 128 x (c1-c0)*128 elements on EVERY rank
+# (its tile rows from group floor(c0/P) down), one equal-count all-gather.  (Tile rows that start inside the range carry
+# their above-diagonal tiles as padding: 5.4 % of the bytes at N = 16384 with 1024-column ranges.)  Mirrors
+# csrc/internal.hpp ColPieces.
 
-MAX_COL_PIECES = 16
+MAX_COL_PIECES = 32
 
 
 def tile_rows(n: int) -> int:
@@ -166,18 +167,28 @@ def rank_tile_rows(n: int, world: int, rank: int):
     return out
 
 
-def default_col_pieces(n: int, world: int, first_cols: int = 1024, max_pieces: int = 16):
-    """Tile-column boundaries [0, c1, ..., T] of the exchange: ranges of one super-panel of the factorisation (1024
-    columns) each -- the first panel chain waits for piece 0 only, the update that follows it for piece 1, and a narrow
-    range carries little above-diagonal padding ((w-1)/(T+1) of the bytes for w tile columns: 5.4 % at N = 16384) --
-    widened so that there are at most `max_pieces` of them (N = 32768: 2048 columns, that factorisation's own first
-    super-panel).  Boundaries are multiples of `world` (equal counts on every rank)."""
+def default_col_pieces(n: int, world: int, first_cols: int = 1024, head_cols: int = 256, max_pieces: int = 20):
+    """Tile-column boundaries [0, c1, ..., T] of the exchange.  The first super-panel of the factorisation (1024 columns)
+    goes out in `head_cols` = 256-column ranges: its first two sub-panels wait for 256 columns only -- 15 MB per rank at
+    N = 16384 on 8 GPUs instead of 59 MB -- and the update behind them for the rest of the super-panel.  Everything beyond
+    goes out in ranges of one super-panel (1024 columns) each, widened so that there are at most `max_pieces` in all
+    (N = 32768: 2048 columns); a narrow range carries little above-diagonal padding ((w-1)/(T+1) of the bytes for w tile
+    columns: 5.4 % at N = 16384).  Any ascending boundaries are legal (a range that does not start on a multiple of `world`
+    carries at most one padding strip per rank)."""
     if n <= 0 or world <= 0:
         raise ValueError("n and world must be positive")
     t_all = tile_rows(n)
-    up = lambda v: -(-v // world) * world          # noqa: E731
-    w = up(max(1, first_cols // TILE, -(-t_all // min(max_pieces, MAX_COL_PIECES))))
-    cols = list(range(0, t_all, w)) + [t_all]
+    first = max(1, first_cols // TILE)
+    head = max(1, head_cols // TILE)
+    cols = [0]
+    if world > 1 and t_all > first:
+        cols = list(range(0, first, head))                       # [0, 2, 4, 6] at the defaults
+        start = first
+    else:
+        start = 0
+    left = max(1, min(max_pieces, MAX_COL_PIECES) - (len(cols) if start else 0))
+    w = max(first, -(-(t_all - start) // left))
+    cols = (cols if start else []) + list(range(start, t_all, w)) + [t_all]
     return cols
 
 
@@ -191,9 +202,9 @@ def col_layout(n: int, world: int, cols):
         raise ValueError("column pieces must span the tile columns [0, %d) in at most %d pieces" % (t_all, MAX_COL_PIECES))
     slots, width, count, off = [], [], [], [0]
     for g in range(len(cols) - 1):
-        if cols[g + 1] <= cols[g] or cols[g] % world:
-            raise ValueError("piece %d = [%d, %d): boundaries must ascend in multiples of the %d ranks" % (g, cols[g], cols[g + 1], world))
-        slots.append(-(-(t_all - cols[g]) // world))
+        if cols[g + 1] <= cols[g]:
+            raise ValueError("piece %d = [%d, %d): boundaries must ascend" % (g, cols[g], cols[g + 1]))
+        slots.append(-(-t_all // world) - cols[g] // world)
         width.append((cols[g + 1] - cols[g]) * TILE)
         count.append(slots[-1] * TILE * width[-1])
         off.append(off[-1] + count[-1])

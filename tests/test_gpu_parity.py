@@ -1315,7 +1315,8 @@ from _played import play_ranks as _play_ranks  # noqa: E402  (tests/_played.py: 
 
 @pytest.mark.parametrize("n,d,world,cols,dtype", [(1000, 24, 3, [0, 3, 6, 8], np.float32), (2048, 16, 2, None, np.float32),
                                                     (700, 10, 1, [0, 2, 6], np.float32), (1536, 8, 4, [0, 12], np.float32),
-                                                    (1100, 12, 8, [0, 8, 9], np.float64), (3000, 8, 5, None, np.float32)])
+                                                    (1100, 12, 8, [0, 8, 9], np.float64), (3000, 8, 5, None, np.float32),
+                                                    (2000, 8, 4, [0, 1, 3, 6, 7, 16], np.float32), (1300, 6, 8, [0, 2, 4, 6, 8, 11], np.float64)])
 def test_column_first_pieces_assemble_the_same_kernel(L, ctx, n, d, world, cols, dtype):
     """`world` ranks played on one GPU in the cyclic column-first layout: the scattered pieces (smn_shard_scatter_cols into a
     matrix of the caller's) equal the one-launch kernel bit for bit on the lower triangle by 128-column tiles, NNGP and
@@ -1342,9 +1343,8 @@ def test_column_first_pieces_assemble_the_same_kernel(L, ctx, n, d, world, cols,
     for got, want in ((k.numpy(), ref.numpy()), (kt.numpy(), ref_t.numpy())):
         assert np.array_equal(got[own], want[own])
         assert np.isnan(got[~own]).all()
-    if world > 1:
-        with pytest.raises(L.SmnError):                       # boundaries that are not multiples of the world
-            ctx.call("smn_shard_scatter_cols", code, stage.ptr, n, world, 2, S.cols_array([0, 1, S.tile_rows(n)]), 0, k.ptr, n)
+    with pytest.raises(L.SmnError):                           # boundaries must ascend and span every tile column
+        ctx.call("smn_shard_scatter_cols", code, stage.ptr, n, world, 2, S.cols_array([0, S.tile_rows(n), S.tile_rows(n)]), 0, k.ptr, n)
 
 
 @pytest.mark.parametrize("world,order,delay", [(2, "forward", None), (4, "reverse", (2, 20000)), (8, "forward", (2, 30000)),

@@ -204,13 +204,14 @@ def test_cyclic_layout_is_balanced_and_every_column_range_is_an_equal_count_gath
             assert max(tiles) - min(tiles) <= 2 * t_all                         # at most ~one period's worth apart
         cols = S.default_col_pieces(n, w)
         lay = S.col_layout(n, w, cols)
-        assert cols[0] == 0 and cols[-1] == t_all and len(cols) - 1 <= 16
-        assert all(c % w == 0 for c in cols[:-1])
+        assert cols[0] == 0 and cols[-1] == t_all and len(cols) - 1 <= S.MAX_COL_PIECES
+        assert cols == sorted(set(cols))
         seen = set()
         for g in range(len(cols) - 1):
+            base = cols[g] // w * w                              # first tile row of the group the piece starts in
             for r in range(w):
-                # the rank's tile rows from the piece's first column down fit the piece's slots, in order
-                mine = [t for t in S.rank_tile_rows(n, w, r) if t >= cols[g]]
+                # the rank's tile rows from that group down fit the piece's slots, in order
+                mine = [t for t in S.rank_tile_rows(n, w, r) if t >= base]
                 assert len(mine) <= lay["slots"][g]
                 for i, t in enumerate(mine):
                     assert t == S.rank_tile_row(w, r, cols[g] // w + i)
@@ -220,12 +221,15 @@ def test_cyclic_layout_is_balanced_and_every_column_range_is_an_equal_count_gath
             assert lay["count"][g] == lay["slots"][g] * S.TILE * lay["width"][g]
         assert len(seen) == t_all * (t_all + 1) // 2                             # every lower tile in exactly one piece
         assert lay["elems"] == sum(lay["count"])
-    assert S.default_col_pieces(16384, 8) == list(range(0, 129, 8))
-    assert S.default_col_pieces(32768, 8) == list(range(0, 257, 16))
+    # the first super-panel in 256-column ranges (its first sub-panels wait for 15 MB per rank, not 59), then one per super-panel
+    assert S.default_col_pieces(16384, 8) == [0, 2, 4, 6] + list(range(8, 129, 8))
+    assert S.default_col_pieces(32768, 8) == [0, 2, 4, 6] + list(range(8, 256, 16)) + [256]
+    assert S.default_col_pieces(16384, 1) == list(range(0, 129, 8))              # one rank: nothing to wait for
     lay = S.col_layout(16384, 8, S.default_col_pieces(16384, 8))
     assert lay["elems"] * 8 < 1.06 * 128 * 129 // 2 * 128 * 128                  # 5.4 % above-diagonal padding
+    assert 7 * lay["count"][0] * 4 < 15e6                                        # bytes a rank receives for range 0
     with pytest.raises(ValueError):
-        S.col_layout(1000, 3, [0, 4, 8])             # boundaries must be multiples of the world
+        S.col_layout(1000, 3, [0, 4, 4, 8])          # boundaries must ascend
     with pytest.raises(ValueError):
         S.col_layout(1000, 2, [0, 4])                # ... and span every tile column
 
@@ -263,7 +267,7 @@ class _CpuBackend:
             for g in range(len(cols) - 1):
                 if cols[g] > t:
                     break
-                slot = (t - cols[g]) // world
+                slot = t // world - cols[g] // world          # groups below the one the piece starts in
                 assert S.rank_tile_row(world, rank, cols[g] // world + slot) == t
                 c0, c1 = cols[g] * S.TILE, min(re, cols[g + 1] * S.TILE)
                 wd = lay["width"][g]
@@ -349,7 +353,7 @@ def _cols_worker(rank, world, port, n, d, cols, q, with_ntk=False):
 
 
 @pytest.mark.parametrize("n,cols,with_ntk", [(300, None, False), (513, [0, 2, 4, 5], False), (200, [0, 2], False),
-                                              (300, [0, 2, 3], True)])
+                                              (300, [0, 2, 3], True), (700, [0, 1, 3, 6], False)])
 def test_world_size_2_gloo_column_first_driver_with_cpu_backend(n, cols, with_ntk):
     """Two gloo processes run sharding.lml_sharded_cols itself -- the function bench.py --gpus N runs on the GPUs -- with the
     device steps replaced by a CPU backend: one build per rank in the cyclic layout, an all-gather per column range, the
