@@ -91,6 +91,9 @@ int aug_finish(smn_ctx* ctx, int dtype, const Aug& g, const void* y, int64_t ldy
   const int crc = cholesky_padded(ctx, dtype, g.a, g.n_total, g.n_pad, g.lda, n_shift, jitter_abs, ridge_rel, false);
   ctx->chol_prepped = false;
   SMN_TRY(crc);
+  // a column-first exchange: the factorisation has waited for the pieces of the workspace; pieces scattered elsewhere (the NTK
+  // of config 5, smn_shard_exchange_cols_to) ride the same scatter stream -- the call returns behind all of them
+  if (ctx->consume_arrivals) SMN_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_c1, 0));
   double* quad_dev = ctx->d_scal + 8;
   SMN_TRY(extract_posterior(ctx, dtype, g.a, g.lda, g.n_pad, g.t, g.c, mean, cov, ldcov, quad_dev, true));
   double ld = 0.0;

@@ -128,8 +128,8 @@ struct BuildArgs {
   const LayerProg* progs; int64_t tab_bs, out_bs; int nbatch;
 };
 
-// BM = 64 (sharded f32 builds of few tiles only): two workgroups per 128x128 tile, 64 rows each -- a piece of a pipelined shard is
-// about one 128x128 tile per CU, and at that grain the launch ends in a tail as long as a tile; halves end in half of it.
+// BM = 64 (f32 launches of few tiles: a rank's share of a sharded build, small kernels): two workgroups per 128x128 tile, 64
+// rows each -- at about one tile per CU a launch ends in a tail as long as a tile; halves end in half of it.
 template <typename T, int NET, int ACT, bool NTK, int BM = kTile>
 __global__ void __launch_bounds__(256, (sizeof(T) == 8 && NTK) ? 1 : (BM == 64 && !NTK ? 3 : 2)) build_kernel(BuildArgs<T> a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
