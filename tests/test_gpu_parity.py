@@ -929,6 +929,68 @@ def test_find_grid_matches_reference_formulas():
     assert got["best_gaussian"] is not None and got["best_student"] is not None
 
 
+def test_batched_loss_with_the_look_ahead_schedule_is_bit_identical_too(L, ctx):
+    """A batch whose problems are large enough for the look-ahead schedule (two streams, CU-masked far updates): grid.y rides
+    through those launches as well."""
+    from smnngp import sweeps
+    n, d = 8300, 6
+    rng = np.random.default_rng(8300)
+    x = ctx.to_device(rng.standard_normal((n, d)).astype(np.float32))
+    y = ctx.to_device(rng.standard_normal((n, 1)).astype(np.float32))
+    ws, bs, eps = np.array([1.0, 1.5, 0.8]), np.array([0.1, 0.4, 0.0]), np.array([1e-1, 3e-2, 2e-1])
+    lp, quad, logdet, info = C.c_double(), C.c_double(), C.c_double(), C.c_int()
+    want = []
+    for b in range(3):
+        ctx.call("smn_spr_loss", L.F32, L.NET_MLP, L.ACT["relu"], 2, ws[b], bs[b], 1.0, x.ptr, n, d, d, y.ptr, eps[b], 0.0, 1.0,
+                 C.byref(lp), C.byref(quad), C.byref(logdet), C.byref(info))
+        want.append((lp.value, quad.value, logdet.value, info.value))
+    got = sweeps.loss_batch(ctx, x, y, network="mlp", num_hiddens=2, activation="relu", w_std=ws, b_std=bs, last_w_std=1.0, eps=eps)
+    for b in range(3):
+        assert (got[0][b], got[1][b], got[2][b], got[3][b]) == want[b] and want[b][3] == 0
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_mixture_nll_matches_the_reference_formulas(L, ctx, dtype):
+    """smn_mixture_nll against find.py:165-187 written out in NumPy: self-normalised importance weights of the sigma^2 draws,
+    the mixture of normals per test point, with and without an importance ratio, a skipped problem, weights spanning
+    hundreds of nats."""
+    from scipy.special import logsumexp
+    rng = np.random.default_rng(77)
+    g, t, nmix, S, n = 5, 37, 3, 500, 300
+    mean = rng.standard_normal((g, t)).astype(dtype)
+    var = (0.2 + rng.random((g, t))).astype(dtype)
+    quad = 200.0 + 300.0 * rng.random(g)
+    logdet = -50.0 + 100.0 * rng.random(g)
+    skip = np.array([0, 0, 1, 0, 0], dtype=np.int32)
+    y = rng.standard_normal(t)
+    y_mean, y_std = 0.3, 1.7
+    sq = np.ascontiguousarray(0.05 + 3.0 * rng.random((nmix, S)))
+    ratio = np.ascontiguousarray(0.5 + rng.random((nmix, S)))
+    md, vd = ctx.to_device(mean), ctx.to_device(var)
+    pd = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))    # noqa: E731
+    for rt in (None, ratio):
+        out = np.empty((g, nmix))
+        ctx.call("smn_mixture_nll", L.dtype_code(dtype), g, t, md.ptr, vd.ptr, pd(quad), pd(logdet), skip.ctypes.data_as(C.POINTER(C.c_int)),
+                 pd(y), y_mean, y_std, n, nmix, S, pd(sq), None if rt is None else pd(rt), pd(out))
+        for b in range(g):
+            for m in range(nmix):
+                if skip[b]:
+                    assert np.isnan(out[b, m])
+                    continue
+                q = sq[m]
+                lpd = -(n / 2) * np.log(2 * np.pi) - 0.5 * logdet[b] - 0.5 * quad[b] / q - 0.5 * n * np.log(q)
+                w = np.exp(lpd - lpd.max()) * (1.0 if rt is None else rt[m])
+                wb = w / w.sum()
+                mu = mean[b].astype(np.float64) * y_std + y_mean
+                sd = np.sqrt(q[:, None]) * np.sqrt(var[b].astype(np.float64))[None, :] * y_std
+                lps = np.log(wb + 1e-24)[:, None] + O.normal_logpdf(y, mu, sd)
+                want = -np.mean(logsumexp(lps, axis=0))
+                assert abs(out[b, m] - want) < 1e-10 * max(1.0, abs(want)), (b, m)
+    with pytest.raises(L.SmnError):
+        ctx.call("smn_mixture_nll", L.dtype_code(dtype), g, t, md.ptr, vd.ptr, pd(quad), pd(logdet), None, pd(y), y_mean, y_std, n, nmix, 9000,
+                 pd(sq), None, pd(out))
+
+
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("n,d,net,act,layers", [(245, 6, "mlp", "relu", 2), (700, 12, "mlp", "erf", 3), (1300, 20, "resnet", "relu", 2),
                                                  (2048, 8, "mlp", "relu", 4)])
