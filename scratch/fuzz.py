@@ -51,6 +51,69 @@ while time.time() < t_end:
             rk, rt = ofn(xh.astype(np.float64), None, L, act, w, b, lw, ("nngp", "ntk"))
             il = np.tril_indices(n)
             errs = [rel(k.numpy()[il], rk[il]), rel(t2.numpy()[il], rt[il]) / 5]
+        elif kind == "cols":
+            # cyclic column-first shard, `world` ranks played on one GPU, random (also unaligned) column ranges, random arrival order
+            import ctypes as C
+            from smnngp import _lib as LL, sharding as S
+            ctx = LL.default_context()
+            n, d, world = int(rng.integers(2, 1800)), int(rng.integers(1, 40)), int(rng.integers(1, 9))
+            t_all = S.tile_rows(n)
+            cuts = sorted(set(int(v) for v in rng.integers(1, max(2, t_all), size=int(rng.integers(0, 6))) if 0 < v < t_all))
+            cols = [0] + cuts + [t_all]
+            case = (kind, dt.__name__, net, act, L, n, d, world, cols, w, b, lw)
+            xh = rng.standard_normal((n, d)).astype(dt); yh = rng.standard_normal(n).astype(dt)
+            x, y = ctx.to_device(xh), ctx.to_device(yh)
+            code, es = LL.dtype_code(dt), np.dtype(dt).itemsize
+            netc = LL.NET_MLP if net == "mlp" else LL.NET_DENSE_RESNET
+            lay = S.col_layout(n, world, cols)
+            stage = ctx.to_device(np.full(world * lay["elems"], np.nan, dt))
+            ca = S.cols_array(cols)
+            for r in range(world):
+                mine = ctx.to_device(np.full(lay["elems"], np.nan, dt))
+                ctx.call("smn_kernel_mlp_shard_cols", code, netc, LL.ACT[act], L, w, b, lw, x.ptr, n, d, d, world, r, len(cols) - 1, ca, 1, mine.ptr, None)
+                for g in range(len(cols) - 1):
+                    ctx.call("smn_memcpy_d2d", C.c_void_p(stage.ptr.value + es * (world * lay["off"][g] + r * lay["count"][g])),
+                             C.c_void_p(mine.ptr.value + es * lay["off"][g]), es * lay["count"][g])
+                ctx.synchronize()
+                del mine
+            eps = 1e-2 if dt == np.float32 else 1e-6
+            lp, quad, logdet, info = C.c_double(), C.c_double(), C.c_double(), C.c_int()
+            ctx.call("smn_spr_loss", code, netc, LL.ACT[act], L, w, b, lw, x.ptr, n, d, d, y.ptr, eps, 0.0, 1.0, C.byref(lp), C.byref(quad), C.byref(logdet), C.byref(info))
+            want = (lp.value, logdet.value, info.value)
+            ctx.call("smn_shard_begin", code, n, eps)
+            for g in rng.permutation(len(cols) - 1):
+                ctx.call("smn_shard_scatter_cols", code, stage.ptr, n, world, len(cols) - 1, ca, int(g), None, 0)
+            ctx.call("smn_lml_from_shards", code, n, y.ptr, 0.0, 1.0, C.byref(lp), C.byref(quad), C.byref(logdet), C.byref(info))
+            got = (lp.value, logdet.value, info.value)
+            same = got == want or (np.isnan(got[0]) and np.isnan(want[0]) and got[2] == want[2])
+            errs = [0.0 if same else 1.0]
+        elif kind == "batch":
+            import ctypes as C
+            from smnngp import _lib as LL, sweeps
+            ctx = LL.default_context()
+            n, d, t, g = int(rng.integers(1, 900)), int(rng.integers(1, 30)), int(rng.integers(1, 70)), int(rng.integers(1, 9))
+            case = (kind, dt.__name__, net, act, L, n, d, t, g)
+            x = ctx.to_device(rng.standard_normal((n, d)).astype(dt)); y = ctx.to_device(rng.standard_normal((n, 1)).astype(dt))
+            xt = ctx.to_device(rng.standard_normal((t, d)).astype(dt))
+            ws, bs, lws = rng.uniform(0.5, 2.0, g), rng.choice([0.0, 1e-8, 0.1, 0.5, 1.0], g), rng.uniform(0.5, 1.5, g)
+            eps = rng.choice([1e-3, 1e-2, 1e-1], g); dfs = rng.choice([0.0, 3.0, 5.0], g); scs = rng.uniform(0.5, 2.0, g)
+            code = LL.dtype_code(dt); netc = LL.NET_MLP if net == "mlp" else LL.NET_DENSE_RESNET
+            lp, quad, logdet, info = C.c_double(), C.c_double(), C.c_double(), C.c_int()
+            mean_d, cov_d = ctx.empty((t, 1), dt), ctx.empty((t, t), dt)
+            kw = dict(network=net, num_hiddens=L, activation=act, w_std=ws, b_std=bs, last_w_std=lws)
+            gl = sweeps.loss_batch(ctx, x, y, eps=eps, df=dfs, scale=scs, **kw)
+            gm, gc, gi = sweeps.predict_batch(ctx, x, y, xt, diag_reg=eps, full_cov=True, **kw)
+            mism = 0
+            for i in range(g):
+                ctx.call("smn_spr_loss", code, netc, LL.ACT[act], L, ws[i], bs[i], lws[i], x.ptr, n, d, d, y.ptr, eps[i], dfs[i], scs[i],
+                         C.byref(lp), C.byref(quad), C.byref(logdet), C.byref(info))
+                if info.value != gl[3][i] or (info.value == 0 and (lp.value, quad.value, logdet.value) != (gl[0][i], gl[1][i], gl[2][i])):
+                    mism += 1
+                ctx.call("smn_spr_predict", code, netc, LL.ACT[act], L, ws[i], bs[i], lws[i], x.ptr, n, d, xt.ptr, t, d, d, y.ptr, 1, eps[i], 0.0,
+                         mean_d.ptr, cov_d.ptr, t, None, None, C.byref(info))
+                if info.value != gi[i] or (info.value == 0 and not (np.array_equal(mean_d.numpy(), gm[i]) and np.array_equal(cov_d.numpy(), gc[i]))):
+                    mism += 1
+            errs = [float(mism)]
         elif kind == "chol":
             import ctypes as C, scipy.linalg as sla
             from smnngp import _lib as LL
