@@ -10,7 +10,7 @@
 // -y^T K^-1 y drop out of the same trailing update that the factorisation needs anyway, so the
 // path has no separate triangular-solve kernels.
 //
-// Right-looking.  Columns are cut three ways: super-panels of S = 1024 columns, outer panels of 256 inside them,
+// Right-looking.  Columns are cut three ways: super-panels of S = 1024 columns, outer panels of 256 (512 under the look-ahead) inside them,
 // 128-column sub-panels inside those.
 //   panel_kernel   one workgroup per block of rows below the diagonal block; every workgroup re-factors the
 //                  128x128 diagonal block in LDS and carries its own rows through the same column operations
@@ -58,6 +58,7 @@ constexpr int kHalfTileMax = 384;      // ... and of at most this many, 64-row t
 constexpr int kPersistMaxK = 512;      // largest K the persistent trailing kernel takes
 constexpr int kPanelSmallRows = 4096;  // f32 panels with at most this many rows below use 64-row workgroups
 constexpr int64_t kSuperWide = 2048;   // super-panel width while at least ctx->super_wide_rows rows are left (profiles/r02_wide_super_panel_sweep.txt)
+constexpr int64_t kOuterWide = 512;     // outer-panel width under the look-ahead schedule (256 without)
 constexpr int64_t kF0FirstTiles = 2000;   // F1 launches of at most this many tiles start behind F0, not beside it (profiles/r02_f0_first_ab.txt)
 
 template <typename T>
@@ -1214,12 +1215,15 @@ int cholesky_t(smn_ctx* ctx, T* a, int64_t n_total, int64_t n_factor, int64_t ld
   // F1 launches are serial on the bulk stream; F0(s) writes tiles F1(s-1) also writes, so it waits for it (ev_b);
   // F1(s) and the chain of s+1 touch disjoint columns.  Two events, two streams; results are bit-identical to the
   // one-stream order (same launches, same tiles).
-  constexpr int64_t W = 2 * PB;
+  hipStream_t sb = (n_total >= ctx->chain_min_n && ctx->stream_bulk) ? ctx->stream_bulk : nullptr;
+  // Outer panels: 256 columns (one strip of K = 128, then a near update of K = 256); with the look-ahead 512 (strips of K = 128,
+  // 256, 384 through the plain K loop -- the pipelined one measured slower there --, near updates of K = 512: half as many
+  // near launches on the chain; C4 -0.7 %, C5 -0.5 %, C2 and f64 N = 8192 flat: profiles/r04_outer_panel_sweep.txt)
+  const int64_t W = sb ? kOuterWide : 2 * PB;
   int64_t S = ctx->super_panel / W * W;
   if (S < W) S = W;
   int64_t Swide = kSuperWide;
   if (Swide < S) Swide = S;
-  hipStream_t sb = (n_total >= ctx->chain_min_n && ctx->stream_bulk) ? ctx->stream_bulk : nullptr;
   bool bulk_busy = false;
   // ctx->chol_noschur: the trailing block of the appended rows (rows and columns >= n_factor) is neither read nor written
   // -- the caller wants B L^-T only (grad.hip: X = L^-T from B = I, then K~^-1 = X X^T as one full-rate launch), and the
@@ -1270,7 +1274,7 @@ int cholesky_t(smn_ctx* ctx, T* a, int64_t n_total, int64_t n_factor, int64_t ld
         const int64_t w = (s_end - j0 < W) ? s_end - j0 : W;
         for (int64_t js = j0; js < j0 + w; js += PB) {
           SMN_TRY(need_columns(st, js + PB));   // (arrivals: a sub-panel and its strip touch their own 128 columns only)
-          if (js > j0)   // strip: the second sub-panel's 128 columns, K = 128
+          if (js > j0)   // strip: this sub-panel's 128 columns, K = the outer panel's finished columns
             SMN_TRY(launch_update<T>(ctx, st, a, lda, js, js, j0, js - j0, (n_total - js) / kTile, 1, 0));
           SMN_TRY(launch_panel<T>(ctx, st, a, lda, js, n_total, 0));
         }
