@@ -1211,9 +1211,10 @@ def test_analytic_gradient_at_sizes_that_skip_identity_tiles(dtype, n):
 
 
 def test_gradient_factorisation_launches_only_the_live_tiles_of_the_identity_block():
-    """[[K~, .], [I, 0]] factored as a dense 2N x 2N matrix would execute ~2.3 N^3 update flops; with the structural zeros
-    of the identity rows left out of every launch it is ~N^3 (chol N^3/3 + L^-T N^3/3 + L^-T L^-1 N^3/3).  The library counts
-    the flops of the tiles it launches (smn_profile_flops), so this pins the launch shapes, not a timing."""
+    """The rectangle [[K~], [I], [y^T]] factored without its Schur block, then -L^-T L^-1 as one launch: ~N^3 update flops
+    (chol N^3/3 + L^-T N^3/3 + L^-T L^-1 N^3/3) when the structural zeros of the identity rows are left out of every launch
+    (a dense 2N x 2N factorisation would execute ~2.3 N^3).  The library counts the flops of the tiles it launches
+    (smn_profile_flops), so this pins the launch shapes, not a timing."""
     from smnngp import nt_kernels, _lib as L
     from smnngp.spax.kernels import NNGPKernel
     from smnngp.spax.likelihoods import GaussianLikelihood
