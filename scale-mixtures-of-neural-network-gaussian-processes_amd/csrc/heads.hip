@@ -79,7 +79,8 @@ int aug_build(smn_ctx* ctx, const BuildSpec& spec, const Aug& g, const void* x, 
 }
 
 int aug_finish(smn_ctx* ctx, int dtype, const Aug& g, const void* y, int64_t ldy, int64_t n_shift, double jitter_abs,
-               double ridge_rel, void* mean, void* cov, int64_t ldcov, double* quad_h, double* logdet_h, int* info_h) {
+               double ridge_rel, void* mean, void* cov, int64_t ldcov, double* quad_h, double* logdet_h, int* info_h,
+               bool td_identity = false) {
   if (g.c > 48) return smn_fail(ctx, SMN_ENOTSUP, "more than 48 output columns");   // the mailbox holds 62 doubles
   // with an absolute jitter only, the right-hand-side rows, the diagonal shift and the scalar reset are one launch
   const bool prepped = ridge_rel == 0.0 && g.c > 0;
@@ -88,7 +89,9 @@ int aug_finish(smn_ctx* ctx, int dtype, const Aug& g, const void* y, int64_t ldy
   else
     SMN_TRY(set_aug_rows(ctx, dtype, g.a, g.lda, g.n_pad + g.t, g.n_total, y, g.n, g.c, ldy));
   ctx->chol_prepped = prepped;
-  const int crc = cholesky_padded(ctx, dtype, g.a, g.n_total, g.n_pad, g.lda, n_shift, jitter_abs, ridge_rel, false);
+  // identity test rows (the small-N gradient route): whole 128-row tiles of them are skipped where they are structurally zero
+  const int64_t id0 = td_identity ? g.n_pad : -1, id1 = td_identity ? g.n_pad + g.t / kTile * kTile : -1;
+  const int crc = cholesky_padded(ctx, dtype, g.a, g.n_total, g.n_pad, g.lda, n_shift, jitter_abs, ridge_rel, false, id0, id1);
   ctx->chol_prepped = false;
   SMN_TRY(crc);
   // a column-first exchange: the factorisation has waited for the pieces of the workspace; pieces scattered elsewhere (the NTK
@@ -447,20 +450,43 @@ __global__ void identity_block_kernel(T* __restrict__ a, int64_t lda, int64_t n)
 
 }  // namespace
 
-// Analytic gradients (grad.hip): alpha = K~^-1 y and -K~^-1 without a 2N x 2N matrix.  The workspace is the RECTANGLE
+// Analytic gradients (grad.hip): alpha = K~^-1 y and -K~^-1.  Two routes, by size:
+// * n_pad >= kGradRectFromN: WITHOUT a 2N x 2N matrix.  The workspace is the RECTANGLE
 //        [ K~ ]   n_pad rows        (K by the layer recursion of the Gram matrix k0, straight into it)
 //   A =  [ I  ]   n rows            identity block: row i is structurally zero left of column i
 //        [ y^T]   1 row (+ padding)
-// of n_pad columns.  A no-Schur factorisation (cholesky.hip: the appended rows' trailing block is never touched, and here
-// does not exist) leaves L, X = I L^-T = L^-T (upper triangular rows) and z^T = (L^-1 y)^T; then ONE full-rate launch forms
-// -K~^-1 = -X X^T (each tile's K loop starts at its row's first non-zero column) straight into the caller's matrix, and a
-// row pass gives alpha = X z and the quadratic form z^T z.  Same N^3 flops as the joint factorisation of [[K~, .], [I, 0]]
-// (round 3), half its memory (2 N^2 instead of 4 N^2 elements), and the N^3 / 3 of the inverse no longer rides on the panel
-// chain.
+//   of n_pad columns.  A no-Schur factorisation (cholesky.hip: the appended rows' trailing block is never touched, and here
+//   does not exist) leaves L, X = I L^-T = L^-T (upper triangular rows) and z^T = (L^-1 y)^T; then ONE full-rate launch forms
+//   -K~^-1 = -X X^T (each tile's K loop starts at its row's first non-zero column) straight into the caller's matrix, and a
+//   row pass gives alpha = X z and the quadratic form z^T z.  Same N^3 flops as the joint factorisation below, half its memory
+//   (2 N^2 instead of 4 N^2 elements), and the N^3 / 3 of the inverse no longer rides on the panel chain: 49.6 -> 46.0 ms at
+//   N = 16384.
+// * below that: the joint factorisation of [[K~, .], [I, 0], [y^T, 0, 0]] (smn_predict with K_td = I, K_tt = 0, assembled in
+//   the workspace): -K~^-1 and alpha fall out of the Schur complement, whose updates ride in the factorisation's own launches.
+//   At these sizes the factorisation is chain-bound and those updates are free, while the rectangle route's extra launches
+//   are not (N = 4096: 2.08 against 2.22 ms; N = 245: 206 against 221 us; profiles/r04_small_n_latency.txt).
+constexpr int64_t kGradRectFromN = 8192;
+
 int factor_with_identity(smn_ctx* ctx, int dtype, int net, int act, int num_hiddens, double w_std, double b_std,
                          double last_w_std, const void* k0_d, int64_t ldk0, const void* q_d, int64_t n, const void* y_d,
                          double eps_abs, void* alpha_d, void* ninv_d, int64_t ldinv, double* quad_h, double* logdet_h,
                          int* info_h) {
+  if (round_up(n, kTile) < kGradRectFromN) {
+    Aug g;
+    SMN_TRY(aug_alloc(ctx, dtype, n, n, 1, &g));
+    SMN_HIP(ctx, hipMemsetAsync(g.at(n, 0), 0, g.es * (size_t)(g.n_total - n) * (size_t)g.lda, ctx->stream));
+    SMN_TRY(smn_recursion(ctx, dtype, net, act, num_hiddens, w_std, b_std, last_w_std, k0_d, n, n, ldk0, q_d, q_d, 1,
+                          SMN_GET_NNGP, g.a, nullptr, g.lda));
+    if (dtype == SMN_F64)
+      hipLaunchKernelGGL(identity_block_kernel<double>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                         reinterpret_cast<double*>(g.at(g.n_pad, 0)), g.lda, n);
+    else
+      hipLaunchKernelGGL(identity_block_kernel<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                         reinterpret_cast<float*>(g.at(g.n_pad, 0)), g.lda, n);
+    SMN_CHECK_LAUNCH(ctx);
+    SMN_TRY(fill_identity_pad(ctx, dtype, g.a, g.lda, g.n_pad, n));
+    return aug_finish(ctx, dtype, g, y_d, 1, n, eps_abs, 0.0, alpha_d, ninv_d, ldinv, quad_h, logdet_h, info_h, true);
+  }
   const size_t es = dtype_size(dtype);
   const int64_t n_pad = round_up(n, kTile), n_app = round_up(n + 1, kTile), n_total = n_pad + n_app, lda = n_pad;
   void* av = nullptr;
