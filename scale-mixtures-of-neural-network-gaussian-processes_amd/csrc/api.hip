@@ -275,7 +275,7 @@ extern "C" int smn_ctx_create(int device_id, smn_ctx** out) {
   if (const char* e = getenv("SMN_XCD_MAP")) c->xcd_map = e[0] == '1';
   if (const char* e = getenv("SMN_SUPER")) c->super_panel = atol(e);
   if (const char* e = getenv("SMN_SUPER_WIDE_ROWS")) c->super_wide_rows = atol(e);
-  if (const char* e = getenv("SMN_PANEL_LEAF")) c->panel_leaf = e[0] == '0' ? 0 : (e[0] == '2' ? 2 : 1);
+  if (const char* e = getenv("SMN_PANEL_LEAF")) c->panel_leaf = e[0] != '0';
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0)

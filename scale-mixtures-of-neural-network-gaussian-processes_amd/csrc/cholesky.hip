@@ -692,397 +692,6 @@ __global__ void __launch_bounds__(2 * panel_threads(XRV)) panelr_kernel(T* __res
   }
 }
 
-// panelf_kernel — panelr_kernel with the leaf SPLIT between waves (round 4).  In panelr_kernel every row wave factors the
-// diagonal tile again (152 of the leaf's 288 vector instructions) while nothing else can run, and the block update waits
-// behind it.  Here, per 16-column block b:
-//   UF(b)  wave 0 brings the diagonal tile T_b up to date (K = 16 b, one MFMA chain), factors it (d-steps only, keeping
-//          1/sqrt(d_kk)) and publishes the rows of L into the image and the reciprocals beside it -- WHILE every other wave
-//          brings block b's columns of the rows below up to date (MFMA; wave 4 shares wave 0's SIMD, so it gets tiles last
-//          and sends the finished block b-1 to global memory instead).                                     -- barrier B --
-//   S(b)   the row waves carry their rows through the v-steps alone (136 instructions, L and the reciprocals read back from
-//          LDS); the helper waves stage the raw columns of the blocks to come, as before.                  -- barrier A --
-// The factor is off the other waves' critical path and the update runs beside it instead of behind it.  Same arithmetic in
-// the same order as panelr_kernel (the halves of the leaf are its instructions, the K loops are the same): identical bits.
-template <typename T, int XRV = PanelCfg<T>::XR>
-__global__ void __launch_bounds__(2 * panel_threads(XRV)) panelf_kernel(T* __restrict__ a, int64_t lda, int64_t j0,
-                                                                          int64_t rbeg, int64_t n_total,
-                                                                          double* __restrict__ logdet,
-                                                                          int* __restrict__ info, T* __restrict__ ldiag_out,
-                                                                          int64_t id0, int64_t id1, int64_t bstride, int64_t lstride) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int XR = XRV, NTV = panel_threads(XRV), LD = PanelCfg<T>::LD;
-  if (bstride) {
-    a += (int64_t)blockIdx.y * bstride; logdet += blockIdx.y; info += blockIdx.y;
-    if (ldiag_out) ldiag_out += (int64_t)blockIdx.y * lstride;
-  }
-  constexpr int VEC = 16 / sizeof(T);
-  constexpr int CB = 16, NB = PB / CB, VPC = CB / VEC, ROWS = PB + XR;
-  using vec_t = typename Mfma<T>::vec_t;
-  using M = PanelMma<T>;
-  constexpr int NW = NTV / 64;          // row waves; as many helper waves
-  constexpr int RT = ROWS / M::TM;
-  constexpr int NO = 2 * NW - 1;        // waves that take update tiles: everybody but the factor wave
-  constexpr int PARTNER = 4;            // shares wave 0's SIMD (waves w and w + 4 do): a helper wave in every configuration
-  static_assert(NW <= PARTNER && PARTNER < 2 * NW, "wave 4 is a helper wave");
-  static_assert((ROWS * VPC) % NTV == 0, "chunk vectors split evenly over the helper threads");
-  T* S = reinterpret_cast<T*>(smem);        // [PB + XR][LD]
-  T* const rv = S + ROWS * LD;              // [16] 1/sqrt(d_kk) of the block in flight
-  const int tid = threadIdx.x;
-  const int64_t rb = rbeg + (int64_t)blockIdx.x * XR;
-  if (id0 >= 0 && rb >= id0 && rb + XR <= id1 && rb - id0 >= j0 + PB) return;
-  const int nx = (int)max((int64_t)0, min((int64_t)XR, n_total - rb));
-  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int fr = M::frag_row(lane), fk = M::frag_k(lane);
-  // S[t, cn:cn+16] -= S[t, 0:cn] S[cn:cn+16, 0:cn]^T for the 16-row tiles t0 and (if >= 0) t1: two independent accumulators,
-  // one B fragment; fragment reads of K-step s+1 issued in front of the MFMAs of step s (as in panelr_kernel).
-  auto update_at = [&](int cn, int t0, int t1) {
-    if (t0 < 0) return;   // wave-uniform
-    const bool two = t1 >= 0;
-    const int rt0 = t0 * M::TM, rt1 = (two ? t1 : t0) * M::TM;
-    T cv[2][M::ACC];
-#pragma unroll
-    for (int i = 0; i < M::ACC; ++i) {
-      cv[0][i] = S[(rt0 + M::acc_row(lane, i)) * LD + cn + M::acc_col(lane)];
-      cv[1][i] = S[(rt1 + M::acc_row(lane, i)) * LD + cn + M::acc_col(lane)];
-    }
-    typename M::acc_t acc[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int i = 0; i < M::ACC; ++i) acc[j][i] = T(0);
-    const T* pb = &S[(cn + fr) * LD + fk];
-    const T* pa0 = &S[(rt0 + fr) * LD + fk];
-    const T* pa1 = &S[(rt1 + fr) * LD + fk];
-    using cvp = const typename M::vec_t*;
-    const int klast = cn - M::KSTEP;
-    auto kloop = [&](auto twoc) {
-      constexpr bool TWO = decltype(twoc)::value;
-      typename M::vec_t b0, x0, y0, b1, x1, y1;
-      auto rd = [&](typename M::vec_t& bq, typename M::vec_t& xq, typename M::vec_t& yq, int kb) {
-        bq = *reinterpret_cast<cvp>(pb + kb);
-        xq = *reinterpret_cast<cvp>(pa0 + kb);
-        if (TWO) yq = *reinterpret_cast<cvp>(pa1 + kb);
-      };
-      auto mm = [&](const typename M::vec_t& bq, const typename M::vec_t& xq, const typename M::vec_t& yq) {
-#pragma unroll
-        for (int i = 0; i < M::NK; ++i) {
-          M::mma1(acc[0], xq[i], bq[i]);
-          if (TWO) M::mma1(acc[1], yq[i], bq[i]);
-        }
-      };
-      rd(b0, x0, y0, 0);
-      for (int kb = 0;;) {
-        rd(b1, x1, y1, min(kb + M::KSTEP, klast));
-        __builtin_amdgcn_sched_barrier(0);
-        mm(b0, x0, y0);
-        kb += M::KSTEP;
-        if (kb >= cn) break;
-        rd(b0, x0, y0, min(kb + M::KSTEP, klast));
-        __builtin_amdgcn_sched_barrier(0);
-        mm(b1, x1, y1);
-        kb += M::KSTEP;
-        if (kb >= cn) break;
-      }
-    };
-    if (two) kloop(std::true_type{}); else kloop(std::false_type{});
-#pragma unroll
-    for (int i = 0; i < M::ACC; ++i) S[(rt0 + M::acc_row(lane, i)) * LD + cn + M::acc_col(lane)] = cv[0][i] - acc[0][i];
-    if (two) {
-#pragma unroll
-      for (int i = 0; i < M::ACC; ++i) S[(rt1 + M::acc_row(lane, i)) * LD + cn + M::acc_col(lane)] = cv[1][i] - acc[1][i];
-    }
-  };
-  // This wave's tiles of block b's update (rows 16 (b + 1) on): dealt round-robin, wave 4 last and only when the others
-  // already carry two tiles each.
-  // The pool: every wave but 0 and 4.  Tiles are dealt so that the three SIMDs it runs on (wave w sits on SIMD w % 4) carry the
-  // same number: with eight waves round-robin over 1, 2, 3, 5, 6, 7; with six, SIMD 1 has two pool waves (1 and 5: every
-  // sixth tile each) and SIMDs 2 and 3 one (waves 2 and 3: every third).  At most three tiles per wave.
-  constexpr bool SIX = 2 * NW == 6;
-  static_assert(2 * NW == 6 || 2 * NW == 8, "six or eight waves");
-  static_assert(SIX ? RT - 2 <= 10 : RT - 2 <= 18, "at most three update tiles per pool wave");
-  const bool pool = wave != 0 && wave != PARTNER;
-  const int tstart = SIX ? (wave == 5 ? 3 : wave - 1) : (wave < PARTNER ? wave - 1 : wave - 2);
-  const int tstride = SIX ? ((wave == 2 || wave == 3) ? 3 : 6) : 6;
-  auto my_tiles = [&](int b, int& t0, int& t1, int& t2) {
-    const int count = RT - 1 - b;
-    t0 = (pool && tstart < count) ? b + 1 + tstart : -1;
-    t1 = (t0 >= 0 && tstart + tstride < count) ? b + 1 + tstart + tstride : -1;
-    t2 = (t1 >= 0 && tstart + 2 * tstride < count) ? b + 1 + tstart + 2 * tstride : -1;
-  };
-  // The diagonal tile's accumulator, T_t's own rows against themselves over columns [k0, k1): the pool runs it up to the
-  // block before last while the chain is busy elsewhere (kept in LDS, accumulator layout), the factor wave adds the last
-  // block -- the same MFMAs in the same order as one chain.
-  T* const eacc = rv + CB;                  // [2][64][ACC]: tile t in half t & 1 (written during UF(t - 1), read in UF(t))
-  static_assert(CB + 2 * 64 * M::ACC <= NW * CB * kLeafTileLd(sizeof(T)), "the accumulators fit behind the image");
-  auto diag_acc = [&](int t, int k0, int k1, typename M::acc_t& acc) {
-    const T* p = &S[(t * M::TM + fr) * LD + fk];
-    using cvp = const typename M::vec_t*;
-    const int klast = k1 - M::KSTEP;
-    typename M::vec_t x0 = *reinterpret_cast<cvp>(p + k0), x1;
-    for (int kb = k0;;) {   // the read of K-step s + 1 in front of the MFMAs of step s
-      x1 = *reinterpret_cast<cvp>(p + min(kb + M::KSTEP, klast));
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int i = 0; i < M::NK; ++i) M::mma1(acc, x0[i], x0[i]);
-      kb += M::KSTEP;
-      if (kb >= k1) break;
-      x0 = *reinterpret_cast<cvp>(p + min(kb + M::KSTEP, klast));
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int i = 0; i < M::NK; ++i) M::mma1(acc, x1[i], x1[i]);
-      kb += M::KSTEP;
-      if (kb >= k1) break;
-    }
-  };
-  auto early_diag = [&](int t, int k1) {    // accumulator of T_t over columns [0, k1) -> LDS
-    typename M::acc_t acc;
-#pragma unroll
-    for (int i = 0; i < M::ACC; ++i) acc[i] = T(0);
-    diag_acc(t, 0, k1, acc);
-#pragma unroll
-    for (int i = 0; i < M::ACC; ++i) eacc[((t & 1) * 64 + lane) * M::ACC + i] = acc[i];
-  };
-  // Block c's columns are final once every row is solved: they leave for global memory (the appended rows' entries in
-  // place, the factored diagonal block to the side buffer) by `nthr` threads.
-  auto store_out = [&](int c, int t0, auto nthrc) {
-    constexpr int NTHR = decltype(nthrc)::value, IT = (ROWS * VPC + NTHR - 1) / NTHR;
-    vec_t buf[IT];
-    T* dst[IT];
-#pragma unroll
-    for (int u = 0; u < IT; ++u) {
-      const int idx = u * NTHR + t0, r = idx / VPC, v = idx % VPC;
-      dst[u] = nullptr;
-      if (idx < ROWS * VPC && r >= c * CB) {
-        if (r < PB) {
-          if (blockIdx.x == 0 && ldiag_out) dst[u] = ldiag_out + (int64_t)r * PB + c * CB + v * VEC;
-        } else if (r - PB < nx) {
-          dst[u] = a + (rb + (r - PB)) * lda + j0 + c * CB + v * VEC;
-        }
-      }
-      if (dst[u]) buf[u] = *reinterpret_cast<const vec_t*>(&S[r * LD + c * CB + v * VEC]);
-    }
-#pragma unroll
-    for (int u = 0; u < IT; ++u)
-      if (dst[u]) *reinterpret_cast<vec_t*>(dst[u]) = buf[u];
-  };
-#ifdef SMN_PANEL_TIMING   // timeline of wg 0 of the first panel: ticks (100 MHz) since kernel start, per block, per wave, 6 marks
-  int* const tlog = reinterpret_cast<int*>(S + ROWS * LD + NW * CB * kLeafTileLd(sizeof(T)));
-  const long long tl0 = wall_clock64();
-#define TL(b, i) do { if (lane == 0 && blockIdx.x == 0 && j0 == 0) tlog[(wave * NB + (b)) * 6 + (i)] = (int)(wall_clock64() - tl0); } while (0)
-#else
-#define TL(b, i)
-#endif
-  if (wave >= NW) {
-    // ------------------------------------------------------------ helper waves
-    const int hid = tid - NTV;
-    constexpr int CPT = ROWS * VPC / NTV;   // 16-byte vectors of one 16-column chunk per helper thread
-    vec_t cbuf[3][CPT];
-    auto chunk_load = [&](vec_t (&buf)[CPT], int c) {   // columns [16 c, 16 c + 16) of the rows from 16 c down
-#pragma unroll
-      for (int u = 0; u < CPT; ++u) {
-        const int idx = u * NTV + hid, r = idx / VPC, v = idx % VPC;
-        const int64_t grow = r < PB ? j0 + r : rb + (r - PB);
-        vec_t t;
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) t[e] = T(0);
-        if (r >= c * CB && (r < PB || r - PB < nx)) t = *reinterpret_cast<const vec_t*>(&a[grow * lda + j0 + c * CB + v * VEC]);
-        buf[u] = t;
-      }
-    };
-    auto chunk_store = [&](const vec_t (&buf)[CPT], int c) {
-#pragma unroll
-      for (int u = 0; u < CPT; ++u) {
-        const int idx = u * NTV + hid, r = idx / VPC, v = idx % VPC;
-        if (r >= c * CB) *reinterpret_cast<vec_t*>(&S[r * LD + c * CB + v * VEC]) = buf[u];
-      }
-    };
-    auto hblock = [&](int b, auto slotc) {
-      constexpr int SLOT = decltype(slotc)::value;
-      if (b >= NB) return;
-      TL(b, 0);
-      if (b > 0) {
-#ifndef PF_NO_W4OUT
-        if (wave == PARTNER) {                      // beside the factor, not an MFMA in sight (two passes: half the registers)
-          store_out(b - 1, lane, std::integral_constant<int, 128>{});
-          store_out(b - 1, lane + 64, std::integral_constant<int, 128>{});
-        }
-#endif
-        TL(b, 1);
-        int t0, t1, t2;
-        my_tiles(b, t0, t1, t2);
-        update_at(b * CB, t0, t1);
-        update_at(b * CB, t2, -1);
-        if (wave == 2 * NW - 1 && b + 1 < NB) early_diag(b + 1, b * CB);   // the last pool wave: the fewest tiles, and not on the factor's SIMD
-      }
-      TL(b, 2);
-      __syncthreads();                              // B: T_b is factored, block b is up to date in every row below
-      TL(b, 3);
-      if (b + 1 < NB) {                             // chunk b + 1 (requested three chunks ago) goes to LDS: first read behind barrier A
-        chunk_store(cbuf[SLOT], b + 1);
-        if (b + 4 < NB) chunk_load(cbuf[SLOT], b + 4);
-      }
-      TL(b, 4);
-      __syncthreads();                              // A: block b is solved in every row
-      TL(b, 5);
-    };
-    chunk_load(cbuf[1], 1);
-    chunk_load(cbuf[2], 2);
-    chunk_load(cbuf[0], 3);
-#ifdef PF_UNROLL
-    static_assert(NB == 8, "spelled out");
-    hblock(0, std::integral_constant<int, 1>{});
-    hblock(1, std::integral_constant<int, 2>{});
-    hblock(2, std::integral_constant<int, 0>{});
-    hblock(3, std::integral_constant<int, 1>{});
-    hblock(4, std::integral_constant<int, 2>{});
-    hblock(5, std::integral_constant<int, 0>{});
-    hblock(6, std::integral_constant<int, 1>{});
-    hblock(7, std::integral_constant<int, 2>{});
-#else
-    for (int b0 = 0; b0 < NB; b0 += 3) {   // chunk b + 1 lives in slot (b + 1) % 3
-      hblock(b0, std::integral_constant<int, 1>{});
-      hblock(b0 + 1, std::integral_constant<int, 2>{});
-      hblock(b0 + 2, std::integral_constant<int, 0>{});
-    }
-#endif
-  } else {
-    // ------------------------------------------------------------ row waves (wave 0: also the factor wave)
-    const int row = tid, r16 = lane & 15;
-    const bool in_s = row < ROWS;
-    const int srow = in_s ? row : ROWS - 1;
-    {
-      // Block 0 of this wave's own 64 rows, VPC lanes per row (whole 64-byte row pieces per request), into the image.  LDS
-      // operations of one wave execute in order: wave 0 reads the first diagonal tile back without a barrier.
-      vec_t own[VPC];
-#pragma unroll
-      for (int u = 0; u < VPC; ++u) {
-        const int idx = u * 64 + lane, r = wave * 64 + idx / VPC, v = idx % VPC;
-        const int64_t gr = r < PB ? j0 + r : rb + (r - PB);
-        vec_t t;
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) t[e] = T(0);
-        if (r < ROWS && (r < PB || r - PB < nx)) t = *reinterpret_cast<const vec_t*>(&a[gr * lda + j0 + v * VEC]);
-        own[u] = t;
-      }
-#pragma unroll
-      for (int u = 0; u < VPC; ++u) {
-        const int idx = u * 64 + lane, r = wave * 64 + idx / VPC, v = idx % VPC;
-        if (r < ROWS) *reinterpret_cast<vec_t*>(&S[r * LD + v * VEC]) = own[u];
-      }
-    }
-#pragma unroll 1
-    for (int b = 0; b < NB; ++b) {
-      const int cb = b * CB;
-      T D[CB], R[CB];
-      TL(b, 0);
-      if (wave == 0) {
-        if (b > 0) {                                // T_b -= (rows of tile b)(rows of tile b)^T over the finished columns
-          T cv[M::ACC];
-          typename M::acc_t acc;
-#pragma unroll
-          for (int i = 0; i < M::ACC; ++i) {
-            cv[i] = S[(cb + M::acc_row(lane, i)) * LD + cb + M::acc_col(lane)];
-            acc[i] = b > 1 ? eacc[((b & 1) * 64 + lane) * M::ACC + i] : T(0);
-          }
-          diag_acc(b, cb - CB, cb, acc);
-#pragma unroll
-          for (int i = 0; i < M::ACC; ++i) S[(cb + M::acc_row(lane, i)) * LD + cb + M::acc_col(lane)] = cv[i] - acc[i];
-        }
-        TL(b, 1);
-#pragma unroll
-        for (int q = 0; q < VPC; ++q) {
-          const vec_t d = *reinterpret_cast<const vec_t*>(&S[(cb + r16) * LD + cb + q * VEC]);
-#pragma unroll
-          for (int e = 0; e < VEC; ++e) D[q * VEC + e] = d[e];
-        }
-        leaf::factor(D, R);
-        if (lane < CB) {                            // row `lane` of L (right of the diagonal: nothing anybody reads)
-#pragma unroll
-          for (int q = 0; q < VPC; ++q) {
-            vec_t t;
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) t[e] = D[q * VEC + e];
-            *reinterpret_cast<vec_t*>(&S[(cb + lane) * LD + cb + q * VEC]) = t;
-          }
-        } else if (lane == CB) {
-#pragma unroll
-          for (int q = 0; q < VPC; ++q) {
-            vec_t t;
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) t[e] = R[q * VEC + e];
-            *reinterpret_cast<vec_t*>(&rv[q * VEC]) = t;
-          }
-        }
-      } else if (b > 0) {
-        TL(b, 1);
-        int t0, t1, t2;
-        my_tiles(b, t0, t1, t2);
-        update_at(cb, t0, t1);
-        update_at(cb, t2, -1);
-      }
-      TL(b, 2);
-      __syncthreads();   // B
-      TL(b, 3);
-      if (64 * (wave + 1) > cb + CB) {   // wave-uniform: some row of this wave lies below tile b
-        T V[CB];
-#pragma unroll
-        for (int q = 0; q < VPC; ++q) {
-          const vec_t v = *reinterpret_cast<const vec_t*>(&S[srow * LD + cb + q * VEC]);
-          const vec_t d = *reinterpret_cast<const vec_t*>(&S[(cb + r16) * LD + cb + q * VEC]);
-          const vec_t r = *reinterpret_cast<const vec_t*>(&rv[q * VEC]);
-#pragma unroll
-          for (int e = 0; e < VEC; ++e) {
-            V[q * VEC + e] = v[e];
-            D[q * VEC + e] = d[e];
-            R[q * VEC + e] = r[e];
-          }
-        }
-        leaf::solve(D, R, V);
-        if (in_s && row >= cb + CB) {
-#pragma unroll
-          for (int q = 0; q < VPC; ++q) {
-            vec_t t;
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) t[e] = V[q * VEC + e];
-            *reinterpret_cast<vec_t*>(&S[row * LD + cb + q * VEC]) = t;
-          }
-        }
-      }
-      TL(b, 4);
-      __syncthreads();   // A
-      TL(b, 5);
-    }
-  }
-#ifdef SMN_PANEL_TIMING
-  if (tid == 0 && blockIdx.x == 0 && j0 == 0)
-    for (int w = 0; w < 2 * NW; ++w)
-      for (int b = 0; b < NB; ++b)
-        printf("panelf wave %d block %d: UF %5d  %s %5d  %s %5d  B %5d  %s %5d  A %5d\n", w, b, tlog[(w * NB + b) * 6 + 0],
-               w == 0 ? "tile" : "out ", tlog[(w * NB + b) * 6 + 1], w == 0 ? "fact" : "upd ", tlog[(w * NB + b) * 6 + 2],
-               tlog[(w * NB + b) * 6 + 3], w < NW ? "solv" : "chnk", tlog[(w * NB + b) * 6 + 4], tlog[(w * NB + b) * 6 + 5]);
-#endif
-#undef TL
-#ifdef PF_NO_W4OUT
-  for (int c = 0; c + 1 < NB; ++c) store_out(c, tid, std::integral_constant<int, 2 * NTV>{});
-#endif
-  store_out(NB - 1, tid, std::integral_constant<int, 2 * NTV>{});
-  if (blockIdx.x == 0 && tid < 64) {
-    // logdet += 2 sum_j log L_jj; info = first pivot that is not a positive number (d <= 0 came out of the leaf as NaN)
-    const T d0 = S[tid * LD + tid], d1 = S[(tid + 64) * LD + tid + 64];
-    double lg = 2.0 * (log((double)d0) + log((double)d1));
-    int bad = !(d0 > T(0)) ? tid : (!(d1 > T(0)) ? tid + 64 : INT_MAX);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      lg += __shfl_xor(lg, o);
-      bad = min(bad, __shfl_xor(bad, o));
-    }
-    if (tid == 0) {
-      atomicAdd(logdet, lg);
-      if (bad != INT_MAX) atomicMin(info, (int)(j0 + bad + 1));
-    }
-  }
-}
-
 // Lower triangles of ALL factored diagonal blocks: side buffer -> matrix, once, after the last panel
 // (nothing inside the factorisation reads L_kk again; the LML / predictive heads never need it).
 template <typename T>
@@ -1518,7 +1127,7 @@ int launch_panel_x(smn_ctx* ctx, hipStream_t st, T* a, int64_t lda, int64_t j0, 
   if (ctx->panel_leaf && !prefactored) {
     ProfScope ps(ctx, PROF_PANEL, st);
     T* ldiag = reinterpret_cast<T*>(ctx->ws[3]) + (j0 / PB) * (int64_t)(PB * PB);
-    auto kernr = ctx->panel_leaf == 2 ? panelf_kernel<T, XRV> : panelr_kernel<T, XRV>;
+    auto kernr = panelr_kernel<T, XRV>;
     hipLaunchKernelGGL(kernr, dim3(grid, gy), dim3(2 * panel_threads(XRV)), panelr_lds_bytes<T>(XRV), st, a, lda, j0, rbeg, n_total,
                        logdet, info, ldiag, ctx->chol_id0, ctx->chol_id1, bs, ls);
     SMN_CHECK_LAUNCH(ctx);
@@ -1558,11 +1167,6 @@ int set_lds_attrs(smn_ctx* ctx) {
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)panelr_lds_bytes<T>()));
   if constexpr (sizeof(T) == 4 && PanelCfg<T>::XR == 128)
     SMN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(panelr_kernel<T, 64>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)panelr_lds_bytes<T>(64)));
-  SMN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(panelf_kernel<T>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)panelr_lds_bytes<T>()));
-  if constexpr (sizeof(T) == 4 && PanelCfg<T>::XR == 128)
-    SMN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(panelf_kernel<T, 64>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)panelr_lds_bytes<T>(64)));
   SMN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(update_kernel<T, 0>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize,

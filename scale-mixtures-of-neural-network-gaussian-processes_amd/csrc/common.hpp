@@ -70,8 +70,7 @@ struct smn_ctx {
   bool chol_prepped = false;         // the caller has shifted the diagonal and reset logdet / info already (aug_prep)
   std::unordered_map<const void*, size_t> max_lds;   // largest dynamic-LDS size already allowed per kernel (smn_allow_lds)
   bool lds_attrs_done[2] = {false, false};   // hipFuncSetAttribute(MaxDynamicSharedMemorySize) issued for f32 / f64 kernels
-  int panel_leaf = 1;                // panel kernel of the factorisation (env SMN_PANEL_LEAF): 0 panel_kernel (micro-panels in LDS), 1 panelr_kernel
-                                     // (register-resident 16x16 leaf), 2 panelf_kernel (the leaf split between a factor wave and the row waves)
+  bool panel_leaf = true;            // panelr_kernel (register-resident 16x16 leaf) in the factorisation; env SMN_PANEL_LEAF=0: panel_kernel
   bool xcd_map = true;               // XCD-aware patch tile order of launches of 512 tiles and more (env SMN_XCD_MAP=0: linear order)
 };
 

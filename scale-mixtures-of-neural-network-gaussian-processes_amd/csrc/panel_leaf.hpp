@@ -52,29 +52,4 @@ __device__ __forceinline__ void run(double (&D)[16], double (&V)[16]) {
 }
 #undef LEAF_RINV
 
-// The two halves of the leaf for panelf_kernel: ONE wave factors the tile (d-steps; R[k] = 1/sqrt(d_kk) kept), publishes
-// the rows of L and R, and the row waves carry their rows through the v-steps alone.  Same instructions, same bits.
-#define LEAF_RINVR(K) R[K] = rsqrt_pivot(bcast<K>(D[K]));
-__device__ __forceinline__ void factor(float (&D)[16], float (&R)[16]) {
-#define LEAF_FACTOR_F32
-#include "panel_leaf_steps.inc"
-#undef LEAF_FACTOR_F32
-}
-__device__ __forceinline__ void factor(double (&D)[16], double (&R)[16]) {
-#define LEAF_FACTOR_F64
-#include "panel_leaf_steps.inc"
-#undef LEAF_FACTOR_F64
-}
-#undef LEAF_RINVR
-__device__ __forceinline__ void solve(const float (&D)[16], const float (&R)[16], float (&V)[16]) {
-#define LEAF_SOLVE_F32
-#include "panel_leaf_steps.inc"
-#undef LEAF_SOLVE_F32
-}
-__device__ __forceinline__ void solve(const double (&D)[16], const double (&R)[16], double (&V)[16]) {
-#define LEAF_SOLVE_F64
-#include "panel_leaf_steps.inc"
-#undef LEAF_SOLVE_F64
-}
-
 }  // namespace leaf
