@@ -223,6 +223,10 @@ int smn_spr_loss_batch(smn_ctx* ctx, int dtype, int net, int act, int num_hidden
                        const double* eps_abs, const double* df, const double* scale,
                        double* logpdf_h, double* quad_h, double* logdet_h, int* info_h);
 int smn_debug_batch_bytes(smn_ctx* ctx, size_t bytes);
+/* Test hook: smn_spr_loss under the look-ahead (n_total >= 8192) builds the bottom-right corner of the kernel matrix as a second
+ * launch on the bulk stream, beside the first super-panel's panel chain (same tiles, same bits: only the order changes).
+ * on = 0 switches that off (one launch, as every other entry point builds). */
+int smn_debug_split_build(smn_ctx* ctx, int on);
 int smn_spr_predict_batch(smn_ctx* ctx, int dtype, int net, int act, int num_hiddens, int nprob,
                           const double* w_std, const double* b_std, const double* last_w_std,
                           const void* x_d, int64_t n, int64_t ldx, const void* xt_d, int64_t t, int64_t ldxt,

@@ -113,10 +113,10 @@ __global__ void set_aug_rows_kernel(T* __restrict__ a, int64_t lda, int64_t row0
 // the appended right-hand-side rows, the absolute diagonal shift (same arithmetic as diag_shift_kernel) and the reset
 // of the logdet / info scalars.
 template <typename T>
-__global__ void aug_prep_kernel(T* __restrict__ a, int64_t lda, int64_t row0, int64_t ncols, const T* __restrict__ y,
+__global__ void aug_prep_kernel(T* __restrict__ a, int64_t lda, int64_t row0, int64_t col0, int64_t ncols, const T* __restrict__ y,
                                 int64_t n, int64_t c, int64_t ldy, int64_t n_shift, double jitter_abs,
                                 double* __restrict__ logdet, int* __restrict__ info) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t i = col0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // columns [col0, ncols) (a split build preps its corner later)
   const int64_t k = blockIdx.y;
   if (i >= ncols || k >= c) return;
   a[(row0 + k) * lda + i] = i < n ? y[i * ldy + k] : T(0);
@@ -241,12 +241,13 @@ int extract_posterior(smn_ctx* ctx, int dtype, const void* a, int64_t lda, int64
 }
 
 int aug_prep(smn_ctx* ctx, int dtype, void* a, int64_t lda, int64_t row0, int64_t ncols, const void* y, int64_t n,
-             int64_t c, int64_t ldy, int64_t n_shift, double jitter_abs) {
-  if (c <= 0 || n_shift > ncols) return smn_fail(ctx, SMN_EINVAL, "aug_prep: bad sizes");
-  dim3 g((unsigned)((ncols + 255) / 256), (unsigned)c);
+             int64_t c, int64_t ldy, int64_t n_shift, double jitter_abs, int64_t col0, hipStream_t st) {
+  if (c <= 0 || n_shift > ncols || col0 < 0 || col0 >= ncols) return smn_fail(ctx, SMN_EINVAL, "aug_prep: bad sizes");
+  if (!st) st = ctx->stream;
+  dim3 g((unsigned)((ncols - col0 + 255) / 256), (unsigned)c);
   DISPATCH_T(dtype,
-             hipLaunchKernelGGL(aug_prep_kernel<float>, g, dim3(256), 0, ctx->stream, static_cast<float*>(a), lda, row0, ncols, static_cast<const float*>(y), n, c, ldy, n_shift, jitter_abs, ctx->d_scal, ctx->d_info),
-             hipLaunchKernelGGL(aug_prep_kernel<double>, g, dim3(256), 0, ctx->stream, static_cast<double*>(a), lda, row0, ncols, static_cast<const double*>(y), n, c, ldy, n_shift, jitter_abs, ctx->d_scal, ctx->d_info));
+             hipLaunchKernelGGL(aug_prep_kernel<float>, g, dim3(256), 0, st, static_cast<float*>(a), lda, row0, col0, ncols, static_cast<const float*>(y), n, c, ldy, n_shift, jitter_abs, ctx->d_scal, ctx->d_info),
+             hipLaunchKernelGGL(aug_prep_kernel<double>, g, dim3(256), 0, st, static_cast<double*>(a), lda, row0, col0, ncols, static_cast<const double*>(y), n, c, ldy, n_shift, jitter_abs, ctx->d_scal, ctx->d_info));
   SMN_CHECK_LAUNCH(ctx);
   return SMN_OK;
 }
@@ -333,6 +334,9 @@ extern "C" int smn_ctx_destroy(smn_ctx* c) {
   if (c->h_mail) (void)hipHostFree(c->h_mail);
   if (c->ev_a) (void)hipEventDestroy(c->ev_a);
   if (c->ev_b) (void)hipEventDestroy(c->ev_b);
+  if (c->ev_s0) (void)hipEventDestroy(c->ev_s0);
+  if (c->ev_corner) (void)hipEventDestroy(c->ev_corner);
+  if (c->tile_list) (void)hipFree(c->tile_list);
   if (c->ev_c0) (void)hipEventDestroy(c->ev_c0);
   if (c->ev_c1) (void)hipEventDestroy(c->ev_c1);
   if (c->stream_comm) (void)hipStreamDestroy(c->stream_comm);

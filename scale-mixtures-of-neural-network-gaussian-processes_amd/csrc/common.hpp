@@ -66,6 +66,13 @@ struct smn_ctx {
   // elements, its logdet / info in batch_logdet[g] / batch_info[g]; every panel / update launch gets grid.y = batch
   size_t batch_bytes = (size_t)48 << 30;   // workspace budget of one batched pass (smn_debug_batch_bytes)
   int batch = 1; int64_t batch_stride = 0, batch_ldiag_stride = 0; double* batch_logdet = nullptr; int* batch_info = nullptr;
+  // Split build of the headline path (heads.hip aug_build, smn_spr_loss with the look-ahead): the bottom-right corner of the
+  // kernel matrix (tile rows and columns >= corner_tile) is built on the bulk stream BESIDE the first super-panel's panel
+  // chain, which needs none of it; the factorisation takes it as one Arrival.  The two tile orders live in tile_list.
+  int* tile_list = nullptr; int64_t tile_list_cap = 0; int tile_list_tm = 0, tile_list_tb = 0, tile_list_na = 0, tile_list_nb = 0;
+  hipEvent_t ev_s0 = nullptr, ev_corner = nullptr;   // main -> bulk (the first launch is done); bulk -> main (the corner has landed)
+  bool split_build = true;           // smn_debug_split_build
+  int64_t corner_col = 0;            // first column of the corner of the split build in flight (0: none)
   bool chol_noschur = false;         // the factorisation in flight leaves the appended rows' trailing block alone (cholesky.hip)
   bool chol_prepped = false;         // the caller has shifted the diagonal and reset logdet / info already (aug_prep)
   std::unordered_map<const void*, size_t> max_lds;   // largest dynamic-LDS size already allowed per kernel (smn_allow_lds)

@@ -314,6 +314,10 @@ struct TileMap {
   __device__ __forceinline__ bool decode(unsigned b, int& tr, int& tc) const {
     const int chunk = grid >> 3;
     const int l = (int)(b & 7) * chunk + (int)(b >> 3);
+    return decode_linear(l, tr, tc);
+  }
+  // tile l of the patch-major order (host too: the tile lists of a split build are written from it)
+  __host__ __device__ __forceinline__ bool decode_linear(int l, int& tr, int& tc) const {
     if (l >= ntiles) return false;
     if (lower) {
       // patch row q (PS tile rows) holds q full patches and the lower half of a diagonal one: 64 q + 36 tiles, so

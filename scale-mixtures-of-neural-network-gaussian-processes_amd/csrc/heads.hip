@@ -53,9 +53,11 @@ double logpdf_from(double quad, double logdet, int64_t n, double df, double scal
 }
 
 // Fused build of the augmented matrix straight from the inputs.
+// allow_split: the caller goes on to aug_finish with an absolute jitter only (smn_spr_loss): under the look-ahead the
+// bottom-right corner of the matrix is then built on the bulk stream beside the first super-panel's panel chain (run_build).
 int aug_build(smn_ctx* ctx, const BuildSpec& spec, const Aug& g, const void* x, int64_t ldx, const void* xt,
               int64_t ldxt, int64_t d, int nbatch = 0, const double* bw = nullptr, const double* bb = nullptr,
-              const double* blw = nullptr) {
+              const double* blw = nullptr, bool allow_split = false) {
   const int64_t kp = k_pad(spec.dtype, d);
   void* xs = nullptr;
   SMN_TRY(smn_workspace(ctx, 0, g.es * (size_t)kp * (size_t)g.n_total + sizeof(double) * (size_t)g.n_total, &xs));
@@ -75,6 +77,7 @@ int aug_build(smn_ctx* ctx, const BuildSpec& spec, const Aug& g, const void* x, 
   c.get_mask = SMN_GET_NNGP;
   c.out_k = g.a; c.ldo = g.lda;
   c.nbatch = nbatch; c.bw = bw; c.bb = bb; c.blw = blw; c.out_bs = g.n_total * g.lda;   // batched: problem b at a + b * n_total^2
+  c.split_corner = (allow_split && nbatch == 0 && ctx->split_build) ? split_corner_tiles(ctx, g.n_total / kTile) : 0;
   return run_build(ctx, c);
 }
 
@@ -84,15 +87,39 @@ int aug_finish(smn_ctx* ctx, int dtype, const Aug& g, const void* y, int64_t ldy
   if (g.c > 48) return smn_fail(ctx, SMN_ENOTSUP, "more than 48 output columns");   // the mailbox holds 62 doubles
   // with an absolute jitter only, the right-hand-side rows, the diagonal shift and the scalar reset are one launch
   const bool prepped = ridge_rel == 0.0 && g.c > 0;
-  if (prepped)
+  // a split build (aug_build): the corner's columns are prepped behind the corner's own launch, on the bulk stream, and the
+  // factorisation takes them as ONE arrival (cholesky.hip need_columns: whoever first touches those columns waits for it)
+  const int64_t corner = ctx->corner_col;
+  ctx->corner_col = 0;
+  if (corner > 0 && !prepped) SMN_HIP(ctx, hipStreamSynchronize(ctx->stream_bulk));   // (no caller does this: the trace needs every column)
+  const bool split = corner > 0 && prepped && !ctx->consume_arrivals;
+  if (split) {
+    const int64_t sh = jitter_abs != 0.0 ? n_shift : 0;
+    SMN_TRY(aug_prep(ctx, dtype, g.a, g.lda, g.n_pad + g.t, corner, y, g.n, g.c, ldy, std::min(sh, corner), jitter_abs));
+    const int prc = aug_prep(ctx, dtype, g.a, g.lda, g.n_pad + g.t, g.n_total, y, g.n, g.c, ldy, sh, jitter_abs, corner, ctx->stream_bulk);
+    if (prc != SMN_OK) {
+      (void)hipStreamSynchronize(ctx->stream_bulk);
+      return prc;
+    }
+    SMN_HIP(ctx, hipEventRecord(ctx->ev_corner, ctx->stream_bulk));
+    ctx->arrivals.clear();
+    ctx->arrivals.push_back({corner, g.n_total, ctx->ev_corner});
+    ctx->consume_arrivals = true;
+  } else if (prepped) {
+    if (corner > 0) SMN_HIP(ctx, hipStreamSynchronize(ctx->stream_bulk));
     SMN_TRY(aug_prep(ctx, dtype, g.a, g.lda, g.n_pad + g.t, g.n_total, y, g.n, g.c, ldy, jitter_abs != 0.0 ? n_shift : 0, jitter_abs));
-  else
+  } else {
     SMN_TRY(set_aug_rows(ctx, dtype, g.a, g.lda, g.n_pad + g.t, g.n_total, y, g.n, g.c, ldy));
+  }
   ctx->chol_prepped = prepped;
   // identity test rows (the small-N gradient route): whole 128-row tiles of them are skipped where they are structurally zero
   const int64_t id0 = td_identity ? g.n_pad : -1, id1 = td_identity ? g.n_pad + g.t / kTile * kTile : -1;
   const int crc = cholesky_padded(ctx, dtype, g.a, g.n_total, g.n_pad, g.lda, n_shift, jitter_abs, ridge_rel, false, id0, id1);
   ctx->chol_prepped = false;
+  if (split) {   // (the factorisation has made the caller's stream wait for the corner, whatever its return code)
+    ctx->arrivals.clear();
+    ctx->consume_arrivals = false;
+  }
   SMN_TRY(crc);
   // a column-first exchange: the factorisation has waited for the pieces of the workspace; pieces scattered elsewhere (the NTK
   // of config 5, smn_shard_exchange_cols_to) ride the same scatter stream -- the call returns behind all of them
@@ -563,7 +590,7 @@ extern "C" int smn_spr_loss(smn_ctx* ctx, int dtype, int net, int act, int num_h
   Aug g;
   SMN_TRY(aug_alloc(ctx, dtype, n, 0, 1, &g));
   BuildSpec s{dtype, net, act, num_hiddens, w_std, b_std, last_w_std};
-  SMN_TRY(aug_build(ctx, s, g, x_d, ldx, x_d, ldx, d));
+  SMN_TRY(aug_build(ctx, s, g, x_d, ldx, x_d, ldx, d, 0, nullptr, nullptr, nullptr, true));
   double quad = 0.0, ld = 0.0;
   int info = 0;
   SMN_TRY(aug_finish(ctx, dtype, g, y_d, 1, n, eps_abs, 0.0, nullptr, nullptr, 0, &quad, &ld, &info));
@@ -739,6 +766,12 @@ int spr_batch(smn_ctx* ctx, const char* who, int dtype, int net, int act, int nu
 }  // namespace
 
 // Test hook: the workspace budget of one batched pass (default 48 GB; larger batches run in chunks of what fits).
+extern "C" int smn_debug_split_build(smn_ctx* ctx, int on) {
+  if (!ctx) return SMN_EINVAL;
+  ctx->split_build = on != 0;
+  return SMN_OK;
+}
+
 extern "C" int smn_debug_batch_bytes(smn_ctx* ctx, size_t bytes) {
   if (!ctx || bytes == 0) return SMN_EINVAL;
   ctx->batch_bytes = bytes;

@@ -57,8 +57,13 @@ struct BuildCall {
   // batched build (nbatch > 0): the same operands under nbatch layer programs that differ in (w_std, b_std, last_w_std)
   // only -- host arrays bw / bb / blw --, problem g written at out_k + g * out_bs elements
   int nbatch; const double* bw; const double* bb; const double* blw; int64_t out_bs;
+  // split_corner = TB > 0 (symmetric, un-sharded, one problem): the tiles with row AND column >= T - TB go out as a second
+  // launch on the bulk stream; ctx->corner_col / ev_corner tell the factorisation (cholesky.hip need_columns) when they landed
+  int split_corner;
 };
 int run_build(smn_ctx* ctx, const BuildCall& c);
+// TB for a split build of T tile rows on this context (0: do not split)
+int split_corner_tiles(const smn_ctx* ctx, int64_t tiles);
 
 // dst[rows_pad, kp] (ld = kp) <- zero-padded copy of src[n, d]; also q[rows_pad] = ||row||^2 / d.
 int pad_rows(smn_ctx* ctx, int dtype, const void* src, int64_t n, int64_t lds, int64_t d,
@@ -101,8 +106,9 @@ int extract_posterior(smn_ctx* ctx, int dtype, const void* a, int64_t lda, int64
                       void* mean, void* cov, int64_t ldcov, double* quad_dev, bool publish = false);
 // set_aug_rows + absolute diagonal shift + reset of logdet / info in one launch (cholesky_padded then runs with
 // ctx->chol_prepped set and skips its own two)
+// (columns [col0, ncols) only, on stream st: the corner of a split build is prepped behind its own launch)
 int aug_prep(smn_ctx* ctx, int dtype, void* a, int64_t lda, int64_t row0, int64_t ncols, const void* y, int64_t n,
-             int64_t c, int64_t ldy, int64_t n_shift, double jitter_abs);
+             int64_t c, int64_t ldy, int64_t n_shift, double jitter_abs, int64_t col0 = 0, hipStream_t st = nullptr);
 // the mailbox after a launch that published into it (extract_posterior(..., publish = true)): synchronise and read
 int fetch_mail(smn_ctx* ctx, int nq, double* quad_h, double* logdet, int* info);
 int solve_rows_padded(smn_ctx* ctx, int dtype, void* a, int64_t n_total, int64_t n_factor, int64_t lda);

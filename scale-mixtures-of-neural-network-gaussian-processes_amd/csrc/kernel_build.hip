@@ -8,6 +8,7 @@
 //                      into the epilogue, so K0 never exists in HBM
 //   4. recursion_kernel: the same per-element program as an HBM-streaming pass over a stored K0
 //                      (hyper-parameter sweeps that reuse K0; the roofline measurement of a3)
+#include <cmath>
 #include <vector>
 
 #include "gemm_nt.hpp"
@@ -126,6 +127,8 @@ struct BuildArgs {
   // batched build (smn_spr_loss_batch / smn_spr_predict_batch): problem blockIdx.y = the same operands under its own layer
   // program progs[y] (same net, act and depth; its own w, b, last_w), its own table block and its own output matrix
   const LayerProg* progs; int64_t tab_bs, out_bs; int nbatch;
+  // explicit tile order (split build): tile l = tlist[l] = tr | tc << 16, dealt to the XCDs in equal contiguous shares like the map
+  const int* tlist; int tlist_n;
 };
 
 // BM = 64 (f32 launches of few tiles: a rank's share of a sharded build, small kernels): two workgroups per 128x128 tile, 64
@@ -190,7 +193,13 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 8 && NTK) ? 1 : (BM == 64 &
       half = (bid >> 3) & 1;
       bid = ((bid >> 4) << 3) | (bid & 7);
     }
-    if (a.use_map) {
+    if (a.tlist) {
+      const int l = (int)(bid & 7) * (int)(gridDim.x >> 3) + (int)(bid >> 3);
+      if (l >= a.tlist_n) return;
+      const int v = a.tlist[l];
+      tr = v & 0xffff;
+      tc = v >> 16;
+    } else if (a.use_map) {
       if (!a.map.decode(bid, tr, tc)) return;
     } else if (a.symmetric) {
       if (bid >= (unsigned)(a.tiles_n * (a.tiles_n + 1) / 2)) return;
@@ -510,7 +519,7 @@ void set_fast(LayerProg* p, bool ntk) {
 }
 
 template <typename T, int NET, int ACT, bool NTK, int BM = kTile>
-int launch_build_t(smn_ctx* ctx, const BuildArgs<T>& a, int64_t ntiles, size_t lds) {
+int launch_build_t(smn_ctx* ctx, const BuildArgs<T>& a, int64_t ntiles, size_t lds, hipStream_t st) {
   auto kern = build_kernel<T, NET, ACT, NTK, BM>;
   if (BM == 64) {
     ntiles *= 2;
@@ -518,38 +527,68 @@ int launch_build_t(smn_ctx* ctx, const BuildArgs<T>& a, int64_t ntiles, size_t l
   }
   SMN_TRY(smn_allow_lds(ctx, reinterpret_cast<const void*>(kern), lds));
   {
-    ProfScope ps(ctx, PROF_BUILD, ctx->stream);
-    hipLaunchKernelGGL(kern, dim3((unsigned)ntiles, (unsigned)(a.progs ? a.nbatch : 1)), dim3(256), lds, ctx->stream, a);
+    ProfScope ps(ctx, PROF_BUILD, st);
+    hipLaunchKernelGGL(kern, dim3((unsigned)ntiles, (unsigned)(a.progs ? a.nbatch : 1)), dim3(256), lds, st, a);
   }
   SMN_CHECK_LAUNCH(ctx);
   return SMN_OK;
 }
 
 template <typename T, int NET, int ACT>
-int launch_build_n(smn_ctx* ctx, const BuildArgs<T>& a, int64_t ntiles, size_t lds, bool ntk) {
+int launch_build_n(smn_ctx* ctx, const BuildArgs<T>& a, int64_t ntiles, size_t lds, bool ntk, hipStream_t st) {
   if constexpr (sizeof(T) == 4) {
     // f32 launches of few tiles (a rank's share of a sharded build, small kernels): 64-row half tiles.  Measured per rank
     // (profiles/r03_shard_pieces_probe.json): 11-17 % faster for launches of 260-520 tiles, a few % either way around 1000 tiles;
     // the un-sharded 8392-tile build of one GPU is 5 % SLOWER with them (6.97 against 6.6 ms): launches above kHalfTileBuildMax
     // keep the 128-row tile.  (Un-sharded launches too, from 64 tiles on: C2's 528-tile build 0.144 -> 0.118 ms.)
-    if (ntiles <= kHalfTileBuildMax && (a.shard || ntiles >= 64)) {
+    if (ntiles <= kHalfTileBuildMax && (a.shard || ntiles >= 64) && !a.tlist) {
       if (!a.shard) ntiles = (ntiles + 7) / 8 * 8;   // the un-sharded decode pairs the halves inside groups of 16 workgroups
-      return ntk ? launch_build_t<T, NET, ACT, true, 64>(ctx, a, ntiles, lds)
-                 : launch_build_t<T, NET, ACT, false, 64>(ctx, a, ntiles, lds);
+      return ntk ? launch_build_t<T, NET, ACT, true, 64>(ctx, a, ntiles, lds, st)
+                 : launch_build_t<T, NET, ACT, false, 64>(ctx, a, ntiles, lds, st);
     }
   }
-  return ntk ? launch_build_t<T, NET, ACT, true>(ctx, a, ntiles, lds)
-             : launch_build_t<T, NET, ACT, false>(ctx, a, ntiles, lds);
+  return ntk ? launch_build_t<T, NET, ACT, true>(ctx, a, ntiles, lds, st)
+             : launch_build_t<T, NET, ACT, false>(ctx, a, ntiles, lds, st);
 }
 
 template <typename T>
-int launch_build(smn_ctx* ctx, const BuildArgs<T>& a, int64_t ntiles, size_t lds, bool ntk) {
+int launch_build(smn_ctx* ctx, const BuildArgs<T>& a, int64_t ntiles, size_t lds, bool ntk, hipStream_t st = nullptr) {
   const int net = a.prog.net, act = a.prog.act;
-  if (net == NET_NONE) return launch_build_t<T, NET_NONE, ACT_RELU, false>(ctx, a, ntiles, lds);
-  if (net == NET_MLP && act == ACT_RELU) return launch_build_n<T, NET_MLP, ACT_RELU>(ctx, a, ntiles, lds, ntk);
-  if (net == NET_MLP && act == ACT_ERF) return launch_build_n<T, NET_MLP, ACT_ERF>(ctx, a, ntiles, lds, ntk);
-  if (net == NET_RESNET && act == ACT_RELU) return launch_build_n<T, NET_RESNET, ACT_RELU>(ctx, a, ntiles, lds, ntk);
-  return launch_build_n<T, NET_RESNET, ACT_ERF>(ctx, a, ntiles, lds, ntk);
+  if (!st) st = ctx->stream;
+  if (net == NET_NONE) return launch_build_t<T, NET_NONE, ACT_RELU, false>(ctx, a, ntiles, lds, st);
+  if (net == NET_MLP && act == ACT_RELU) return launch_build_n<T, NET_MLP, ACT_RELU>(ctx, a, ntiles, lds, ntk, st);
+  if (net == NET_MLP && act == ACT_ERF) return launch_build_n<T, NET_MLP, ACT_ERF>(ctx, a, ntiles, lds, ntk, st);
+  if (net == NET_RESNET && act == ACT_RELU) return launch_build_n<T, NET_RESNET, ACT_RELU>(ctx, a, ntiles, lds, ntk, st);
+  return launch_build_n<T, NET_RESNET, ACT_ERF>(ctx, a, ntiles, lds, ntk, st);
+}
+
+// Tile orders of a split build of T tile rows with a corner of TB: the XCD patch order of the whole triangle, filtered into
+// "everything but the corner" (na tiles, at tile_list) and "the corner" (nb tiles, behind them).  Cached per (T, TB).
+int split_tile_lists(smn_ctx* ctx, int T, int TB) {
+  if (ctx->tile_list && ctx->tile_list_tm == T && ctx->tile_list_tb == TB) return SMN_OK;
+  const TileMap map = TileMap::make(T, T, 1);
+  std::vector<int> la, lb;
+  la.reserve((size_t)map.ntiles);
+  for (int l = 0; l < map.ntiles; ++l) {
+    int tr = 0, tc = 0;
+    if (!map.decode_linear(l, tr, tc)) return smn_fail(ctx, SMN_EINVAL, "split_tile_lists: tile order");
+    ((tr >= T - TB && tc >= T - TB) ? lb : la).push_back(tr | (tc << 16));
+  }
+  if ((int64_t)lb.size() != (int64_t)TB * (TB + 1) / 2) return smn_fail(ctx, SMN_EINVAL, "split_tile_lists: corner count");
+  // (a kernel of an earlier call may still read the old lists only if that call failed half-way: drain before rewriting)
+  SMN_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->stream_bulk) SMN_HIP(ctx, hipStreamSynchronize(ctx->stream_bulk));
+  if (ctx->tile_list_cap < map.ntiles) {
+    if (ctx->tile_list) (void)hipFree(ctx->tile_list);
+    ctx->tile_list = nullptr; ctx->tile_list_cap = 0; ctx->tile_list_tm = 0;
+    SMN_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->tile_list), sizeof(int) * (size_t)map.ntiles));
+    ctx->tile_list_cap = map.ntiles;
+  }
+  ctx->tile_list_tm = 0;
+  SMN_HIP(ctx, hipMemcpy(ctx->tile_list, la.data(), sizeof(int) * la.size(), hipMemcpyHostToDevice));
+  SMN_HIP(ctx, hipMemcpy(ctx->tile_list + la.size(), lb.data(), sizeof(int) * lb.size(), hipMemcpyHostToDevice));
+  ctx->tile_list_tm = T; ctx->tile_list_tb = TB; ctx->tile_list_na = (int)la.size(); ctx->tile_list_nb = (int)lb.size();
+  return SMN_OK;
 }
 
 template <typename T>
@@ -617,6 +656,7 @@ int run_build_t(smn_ctx* ctx, const BuildCall& c) {
   a.use_map = 0;
   a.map = TileMap::make(tm, tn, c.symmetric);
   a.shard = c.shard;
+  a.tlist = nullptr; a.tlist_n = 0;
   if (c.shard == 2) {
     if (!c.symmetric) return smn_fail(ctx, SMN_EINVAL, "run_build: shard mode needs the symmetric operands");
     a.cy_P = c.cy_P; a.cy_rank = c.cy_rank; a.cy_T = (int)tm; a.cy_np = c.cy_np;
@@ -655,8 +695,32 @@ int run_build_t(smn_ctx* ctx, const BuildCall& c) {
   size_t lds = MainTile<T>::LDS_BYTES;
   const size_t tab_lds = (size_t)(prog.nsets * 2 + 1) * 2 * kTile * sizeof(T);
   if (tab_lds > lds) lds = tab_lds;
+  ctx->corner_col = 0;
+  if (c.split_corner > 0 && c.symmetric && !c.shard && c.nbatch == 0 && !c.mirror && ctx->stream_bulk && c.split_corner < tm) {
+    // Two launches: everything but the bottom-right corner on the caller's stream, the corner on the bulk stream (CU-masked,
+    // like the far updates it will be followed by) -- beside whatever the caller issues next on its own stream.
+    const int TB = c.split_corner;
+    SMN_TRY(split_tile_lists(ctx, (int)tm, TB));
+    if (!ctx->ev_s0) SMN_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_s0, hipEventDisableTiming));
+    if (!ctx->ev_corner) SMN_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_corner, hipEventDisableTiming));
+    a.use_map = 0;
+    a.tlist = ctx->tile_list; a.tlist_n = ctx->tile_list_na;
+    SMN_TRY(launch_build<T>(ctx, a, (a.tlist_n + 7) / 8 * 8, lds, ntk, ctx->stream));
+    // the corner starts BEHIND the first launch (it is meant to share the chip with the panel chain, not with the build)
+    SMN_HIP(ctx, hipEventRecord(ctx->ev_s0, ctx->stream));
+    SMN_HIP(ctx, hipStreamWaitEvent(ctx->stream_bulk, ctx->ev_s0, 0));
+    a.tlist = ctx->tile_list + ctx->tile_list_na; a.tlist_n = ctx->tile_list_nb;
+    const int rc = launch_build<T>(ctx, a, (a.tlist_n + 7) / 8 * 8, lds, ntk, ctx->stream_bulk);
+    if (rc != SMN_OK) {   // the corner did not go out: nothing on the bulk stream to wait for, but the matrix is incomplete
+      (void)hipStreamSynchronize(ctx->stream);
+      return rc;
+    }
+    ctx->corner_col = (tm - TB) * kTile;
+    return SMN_OK;
+  }
   return launch_build<T>(ctx, a, ntiles, lds, ntk);
 }
+
 
 template <typename T, int NET, int ACT, bool NTK>
 int launch_rec_t(smn_ctx* ctx, const RecArgs<T>& a, dim3 grid, size_t lds) {
@@ -759,6 +823,26 @@ int pad_rows(smn_ctx* ctx, int dtype, const void* src, int64_t n, int64_t lds, i
 
 int run_build(smn_ctx* ctx, const BuildCall& c) {
   return c.spec.dtype == SMN_F64 ? run_build_t<double>(ctx, c) : run_build_t<float>(ctx, c);
+}
+
+// Size of the corner of a split build: the corner's tiles take about as long on the bulk stream's CUs as the first
+// super-panel's panel chain (1.2 ms at N = 16384: 8 sub-panels at 71 us on the reserved CUs, strips, two near updates), and
+// what is left fills a whole number of rounds of two workgroups per CU as nearly as possible.  Measured
+// (profiles/r04_split_build.txt): N = 16384 20.90 -> 20.68 ms, N = 32768 105.40 -> 105.34; N = 8000 and 12345 lose 0.5-1 %
+// (their first chain is shorter than any corner worth a launch): only from 112 tile rows on.
+int split_corner_tiles(const smn_ctx* ctx, int64_t tiles) {
+  if (!ctx->stream_bulk || tiles * kTile < ctx->chain_min_n || tiles < 112 || tiles > 0x7fff) return 0;
+  const int64_t total = tiles * (tiles + 1) / 2, round = 2 * (int64_t)ctx->num_cu;
+  int best = 0;
+  double best_fill = -1.0;
+  for (int tb = 32; tb <= 56; ++tb) {
+    const int64_t na = total - (int64_t)tb * (tb + 1) / 2;
+    const double r = (double)na / (double)round;
+    const double fill = r - std::floor(r);            // 0.98 = the last round almost full; 0.0 = exactly full
+    const double score = fill < 1e-9 ? 1.0 : fill;
+    if (score > best_fill) { best_fill = score; best = tb; }
+  }
+  return best;
 }
 
 // ------------------------------------------------------------------ public entry points

@@ -113,6 +113,18 @@ def test_c4_fused_unfused_and_sharded_routes_and_permutation_invariance(L, ctx, 
     fused = (lp.value, quad.value, logdet.value)
     assert info.value == 0 and np.isfinite(fused).all()
     assert abs(fused[0] - (-0.5 * fused[1] - 0.5 * n * np.log(2 * np.pi) - 0.5 * fused[2])) < 1e-9 * abs(fused[0])
+    # at this size the call above built the matrix's corner as a second launch on the bulk stream, beside the first panel chain
+    # (csrc/kernel_build.hip split build); the single launch gives the same bits, and so does the split build again
+    try:
+        ctx.call("smn_debug_split_build", 0)
+        ctx.call("smn_spr_loss", L.F32, L.NET_MLP, L.ACT["relu"], 4, 1.0, 1e-8, 1.0, x.ptr, n, d, d, y.ptr, eps, 0.0, 1.0,
+                 C.byref(lp), C.byref(quad), C.byref(logdet), C.byref(info))
+    finally:
+        ctx.call("smn_debug_split_build", 1)
+    assert info.value == 0 and (lp.value, quad.value, logdet.value) == fused
+    ctx.call("smn_spr_loss", L.F32, L.NET_MLP, L.ACT["relu"], 4, 1.0, 1e-8, 1.0, x.ptr, n, d, d, y.ptr, eps, 0.0, 1.0,
+             C.byref(lp), C.byref(quad), C.byref(logdet), C.byref(info))
+    assert info.value == 0 and (lp.value, quad.value, logdet.value) == fused
     # Student-t head from the same (quad, logdet): spax/utils.py:178-183
     df, scale = 4.0, 1.5
     ctx.call("smn_spr_loss", L.F32, L.NET_MLP, L.ACT["relu"], 4, 1.0, 1e-8, 1.0, x.ptr, n, d, d, y.ptr, eps, df, scale,

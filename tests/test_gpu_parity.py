@@ -664,6 +664,36 @@ def test_panel_register_leaf_agrees_with_the_lds_micro_panel_kernel(L, dtype, n,
     assert out[1][0] == out[2][0] and np.array_equal(out[1][1][il], out[2][1][il])
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_split_build_of_the_fused_loss_gives_the_single_launch_bits(L, ctx, dtype):
+    """smn_spr_loss from 112 tile rows on (look-ahead on) builds the bottom-right corner of the kernel matrix as a second launch
+    on the bulk stream, beside the first super-panel's panel chain; the factorisation waits for it where it first touches those
+    columns (kernel_build.hip run_build_t, heads.hip aug_finish, cholesky.hip need_columns).  Same tiles, same arithmetic: the
+    single launch's bits, twice; and a matrix that is not positive definite in its FIRST columns (the factorisation gives up
+    while the corner is still in flight) comes back as info != 0 with the context usable afterwards."""
+    n, d = 14400, 48
+    rng = np.random.default_rng(14)
+    x = ctx.to_device(rng.standard_normal((n, d)).astype(dtype))
+    y = ctx.to_device(rng.standard_normal((n, 1)).astype(dtype))
+
+    def loss(eps):
+        lp, quad, logdet, info = C.c_double(), C.c_double(), C.c_double(), C.c_int()
+        ctx.call("smn_spr_loss", L.dtype_code(dtype), L.NET_MLP, L.ACT["relu"], 2, 1.0, 0.3, 1.0, x.ptr, n, d, d, y.ptr, eps, 0.0, 1.0,
+                 C.byref(lp), C.byref(quad), C.byref(logdet), C.byref(info))
+        return lp.value, quad.value, logdet.value, info.value
+
+    split = [loss(1e-2), loss(1e-2)]
+    try:
+        ctx.call("smn_debug_split_build", 0)
+        single = loss(1e-2)
+    finally:
+        ctx.call("smn_debug_split_build", 1)
+    assert single[3] == 0 and split[0] == single and split[1] == single
+    bad = loss(-5.0)                       # K - 5 I: the first pivot is already negative
+    assert bad[3] == 1 and np.isnan(bad[0])
+    assert loss(1e-2) == single
+
+
 @pytest.mark.parametrize("dtype,n,m", [(np.float32, 9216, 128), (np.float64, 8192, 0)])
 def test_cholesky_lookahead_is_bitwise_reproducible(L, ctx, dtype, n, m):
     """The look-ahead runs the block updates on a second stream beside the next block's panel chain.  A missing
@@ -1210,16 +1240,19 @@ def test_analytic_gradient_at_sizes_that_skip_identity_tiles(dtype, n):
         assert abs(got - ref[k]) < tol * max(scale, abs(ref[k])), (k, got, ref[k])
 
 
-def test_gradient_factorisation_launches_only_the_live_tiles_of_the_identity_block():
-    """The rectangle [[K~], [I], [y^T]] factored without its Schur block, then -L^-T L^-1 as one launch: ~N^3 update flops
-    (chol N^3/3 + L^-T N^3/3 + L^-T L^-1 N^3/3) when the structural zeros of the identity rows are left out of every launch
-    (a dense 2N x 2N factorisation would execute ~2.3 N^3).  The library counts the flops of the tiles it launches
-    (smn_profile_flops), so this pins the launch shapes, not a timing."""
+@pytest.mark.parametrize("n", [4096, 8192])
+def test_gradient_factorisation_launches_only_the_live_tiles_of_the_identity_block(n):
+    """Both routes of the gradient's factorisation (heads.hip factor_with_identity): below 8192 rows the joint matrix
+    [[K~, .], [I, 0], [y^T, 0, 0]], whose Schur complement is -K~^-1; from 8192 on the rectangle [[K~], [I], [y^T]] factored
+    without its Schur block, then -L^-T L^-1 as one launch.  Either way ~N^3 update flops (chol N^3/3 + L^-T N^3/3 +
+    L^-T L^-1 N^3/3) when the structural zeros of the identity rows are left out of every launch (a dense 2N x 2N
+    factorisation would execute ~2.3 N^3).  The library counts the flops of the tiles it launches (smn_profile_flops), so
+    this pins the launch shapes, not a timing."""
     from smnngp import nt_kernels, _lib as L
     from smnngp.spax.kernels import NNGPKernel
     from smnngp.spax.likelihoods import GaussianLikelihood
     from smnngp.spax.models import SPR
-    n, d = 4096, 64
+    d = 64
     rng = np.random.default_rng(5)
     x = rng.standard_normal((n, d)).astype(np.float32); y = rng.standard_normal(n).astype(np.float32)
     kernel = NNGPKernel(lambda w, b, l: nt_kernels.get_mlp_kernel(2, 1, act="relu", w_std=w, b_std=b, last_w_std=l), 1.0, 0.3, 1.0)
@@ -1235,8 +1268,8 @@ def test_gradient_factorisation_launches_only_the_live_tiles_of_the_identity_blo
         fl += v.value
     assert np.isfinite(loss) and all(np.isfinite(g) for g in grads.values())
     assert 0.9 * n ** 3 < fl < 1.45 * n ** 3, fl / n ** 3      # whole 128 x 128 tiles: a little above N^3 at this size
-    # at this size the joint factorisation runs with the look-ahead (two streams, CU mask) AND the launch split: its loss must
-    # be SPR.loss's, and its w_std gradient the central difference of SPR.loss (the one-stream, un-hinted factorisation)
+    # at these sizes the factorisation runs with the look-ahead (two streams, CU mask) AND the launch split: its loss must
+    # be SPR.loss's, and its w_std gradient the central difference of SPR.loss (the un-hinted factorisation)
     assert abs(loss - model.loss()) < 2e-5 * abs(loss)
     name = [k for k in grads if k.endswith("w_std") and "last" not in k][0]
     raw, h = kernel.w_std.value.copy(), 2e-2
@@ -1247,6 +1280,14 @@ def test_gradient_factorisation_launches_only_the_live_tiles_of_the_identity_blo
     kernel.w_std.value = raw
     fd = (lp - lm) / (2 * h)
     assert abs(grads[name] - fd) < 0.03 * abs(fd) + 2e-4, (grads[name], fd)
+    if n == 8192:   # the rectangle route against the oracle's central differences (two of the six; fp64 on the host, ~10 s)
+        ref = O.spr_loss_grad_fd(x.astype(np.float64), y.astype(np.float64), keys=("w_std", "eps"), kernel="mlp", num_hiddens=2,
+                                 act="relu", method="gp", w_std=1.0, b_std=0.3, last_w_std=1.0, eps=1e-2)
+        names = {id(v): k for k, v in model.vars().items()}
+        scale = max(abs(v) for v in ref.values())
+        for key, var in (("w_std", kernel.w_std), ("eps", model.eps)):
+            got = grads[names[id(var)]] / float(var.constraint.grad(var.value))
+            assert abs(got - ref[key]) < 2e-2 * max(scale, abs(ref[key])), (key, got, ref[key])
 
 
 def test_device_matrix_hands_over_its_diagonal_without_a_full_download():
