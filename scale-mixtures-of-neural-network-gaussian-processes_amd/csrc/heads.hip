@@ -77,7 +77,8 @@ int aug_build(smn_ctx* ctx, const BuildSpec& spec, const Aug& g, const void* x, 
   c.get_mask = SMN_GET_NNGP;
   c.out_k = g.a; c.ldo = g.lda;
   c.nbatch = nbatch; c.bw = bw; c.bb = bb; c.blw = blw; c.out_bs = g.n_total * g.lda;   // batched: problem b at a + b * n_total^2
-  c.split_corner = (allow_split && nbatch == 0 && ctx->split_build) ? split_corner_tiles(ctx, g.n_total / kTile) : 0;
+  // (not while pieces of a column-first exchange are pending on this context: the Arrival list is theirs)
+  c.split_corner = (allow_split && nbatch == 0 && ctx->split_build && ctx->arrivals.empty()) ? split_corner_tiles(ctx, g.n_total / kTile) : 0;
   return run_build(ctx, c);
 }
 
