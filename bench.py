@@ -1004,6 +1004,10 @@ def main():
         build_wall_ms = per["build"][0]
         chol_wall_ms = ms_per_step - build_wall_ms - per["prep"][0] - (0.0 if sharded else per["misc"][0]) - per["exposed"][0]
         roof["cholesky_wall_ms"] = chol_wall_ms
+        if not sharded and t >= 112 and lookahead:
+            roof["cholesky_wall_note"] = ("split build: the kernel matrix's corner (a second build launch, ~1.2 ms of phases_ms.build at "
+                                          "C4) runs beside the factorisation's first panel chain; cholesky_wall_ms = step - build launches - "
+                                          "prep, i.e. that overlap is booked to the build")
         # every MFMA flop of the factorisation (trailing + strip updates) over its wall time, panel chain included
         roof["cholesky_mfma_frac"] = (trail_fl + strip_fl) / (chol_wall_ms * 1e-3) / 1e12 / peak
         roof["lookahead"] = bool(lookahead)

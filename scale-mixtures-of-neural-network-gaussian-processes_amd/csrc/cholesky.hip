@@ -56,7 +56,10 @@ constexpr int MP = 8;    // micro-panel width of the in-LDS factorisation
 constexpr int kQuarterTileMax = 256;   // update launches of at most this many 128x128 tiles use 64x64 tiles
 constexpr int kHalfTileMax = 384;      // ... and of at most this many, 64-row tiles
 constexpr int kPersistMaxK = 512;      // largest K the persistent trailing kernel takes
-constexpr int kPanelSmallRows = 4096;  // f32 panels with at most this many rows below use 64-row workgroups
+constexpr int kPanelSmallRows = 4096;  // f32 panels with at most this many rows below use 16-row workgroups (kPanelSmallXR): the chain-bound
+constexpr int kPanelSmallXR = 16;      // tail and small problems.  At most 256 of them, one per CU, each with the least block-update work
+                                       // behind its (redundant) factorisation of the diagonal block; batches that fill the chip keep 64-row
+                                       // ones (launch_panel).  Against 64-row ones and other thresholds: profiles/r04_panel_rows_ab.txt
 constexpr int64_t kSuperWide = 2048;   // super-panel width while at least ctx->super_wide_rows rows are left (profiles/r02_wide_super_panel_sweep.txt)
 constexpr int64_t kOuterWide = 512;     // outer-panel width under the look-ahead schedule (256 without)
 constexpr int64_t kF0FirstTiles = 2000;   // F1 launches of at most this many tiles start behind F0, not beside it (profiles/r02_f0_first_ab.txt)
@@ -157,8 +160,8 @@ __device__ __forceinline__ double rsqrt_t(double x) { return 1.0 / sqrt(x); }
 // 27 us per sub-panel against 29 -- is superseded by panelr_kernel below and gone from the source: profiles/r02_panel_helpers_ab.txt.)
 // prefactored != 0: the diagonal block already holds L (solve only; used by smn_trsm).
 // XRV = rows below the diagonal block carried per workgroup.  The default (128 in f32) minimises the number of
-// workgroups that each redo the diagonal factorisation; the f32 64-row form is launched when the panel has few
-// row blocks anyway (late, chain-bound super-panels): the MFMA block updates of a workgroup shrink by a quarter.
+// workgroups that each redo the diagonal factorisation; the f32 16-row form (kPanelSmallXR) is launched when the panel has few
+// rows anyway (late, chain-bound super-panels; small problems): the MFMA block updates of a workgroup shrink by half.
 template <typename T, int XRV = PanelCfg<T>::XR>
 __global__ void __launch_bounds__(panel_threads(XRV)) panel_kernel(T* __restrict__ a, int64_t lda, int64_t j0,
                                                                      int64_t rbeg, int64_t n_total, int prefactored,
@@ -1147,8 +1150,16 @@ int launch_panel_x(smn_ctx* ctx, hipStream_t st, T* a, int64_t lda, int64_t j0, 
 template <typename T>
 int launch_panel(smn_ctx* ctx, hipStream_t st, T* a, int64_t lda, int64_t j0, int64_t n_total, int prefactored) {
   if constexpr (sizeof(T) == 4 && PanelCfg<T>::XR == 128) {
-    // few row blocks left: 64-row workgroups (twice as many, each with a quarter less MFMA work)
-    if (n_total - (j0 + PB) <= (int64_t)kPanelSmallRows) return launch_panel_x<T, 64>(ctx, st, a, lda, j0, n_total, prefactored);
+    // few rows left: 16-row workgroups (eight times as many, each with half the block-update work)
+    const int64_t below = n_total - (j0 + PB);
+    if (below <= (int64_t)kPanelSmallRows) {
+      // latency-bound (one problem, or a batch that does not fill the chip anyway): 16-row workgroups; a batch that does fill
+      // it is throughput-bound, and every workgroup redoes the diagonal block: 64-row ones, a quarter as many
+      const int64_t gy = ctx->batch_logdet ? ctx->batch : 1;
+      if (gy * ((below + kPanelSmallXR - 1) / kPanelSmallXR) <= 2 * (int64_t)ctx->num_cu)
+        return launch_panel_x<T, kPanelSmallXR>(ctx, st, a, lda, j0, n_total, prefactored);
+      return launch_panel_x<T, 64>(ctx, st, a, lda, j0, n_total, prefactored);
+    }
   }
   return launch_panel_x<T, PanelCfg<T>::XR>(ctx, st, a, lda, j0, n_total, prefactored);
 }
@@ -1160,14 +1171,21 @@ int set_lds_attrs(smn_ctx* ctx) {
   SMN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(panel_kernel<T>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)panel_lds_bytes<T>()));
-  if constexpr (sizeof(T) == 4 && PanelCfg<T>::XR == 128)
+  if constexpr (sizeof(T) == 4 && PanelCfg<T>::XR == 128) {
+    SMN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(panel_kernel<T, kPanelSmallXR>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)panel_lds_bytes<T>(kPanelSmallXR)));
     SMN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(panel_kernel<T, 64>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)panel_lds_bytes<T>(64)));
+  }
   SMN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(panelr_kernel<T>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)panelr_lds_bytes<T>()));
-  if constexpr (sizeof(T) == 4 && PanelCfg<T>::XR == 128)
+  if constexpr (sizeof(T) == 4 && PanelCfg<T>::XR == 128) {
+    SMN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(panelr_kernel<T, kPanelSmallXR>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)panelr_lds_bytes<T>(kPanelSmallXR)));
     SMN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(panelr_kernel<T, 64>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)panelr_lds_bytes<T>(64)));
+  }
+
   SMN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(update_kernel<T, 0>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)MainTile<T>::LDS_BYTES));

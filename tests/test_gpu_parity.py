@@ -636,7 +636,7 @@ def test_panel_register_leaf_agrees_with_the_lds_micro_panel_kernel(L, dtype, n,
     streamed in beside the first leaves) against panel_kernel (8-column micro-panels in LDS): two different summation
     orders of the same factorisation, so agreement to accumulation accuracy -- and twice the leaf kernel bit for bit (a
     hand-off between the helper waves and the row threads that came too early or too late would show as a run-to-run
-    difference).  Sizes on both sides of the 64-row / 128-row workgroup switch (4096 rows)."""
+    difference).  Sizes on both sides of the 16-row / 128-row workgroup switch (4096 rows)."""
     import os
     rng = np.random.default_rng(21)
     g = rng.standard_normal((n + m, 64)).astype(dtype)
