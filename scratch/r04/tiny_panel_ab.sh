@@ -1,5 +1,6 @@
 #!/bin/bash
-# 16-row f32 panel workgroups for the last rows (variant builds -DSMN_PANEL_TINY_ROWS=2048 / 4096) against the default (64-row from 4096 rows down)
+# 16-row f32 panel workgroups for the last rows against 64-row ones.  The variants were builds of a working tree that took the threshold
+# as a macro (libsmnngp_tNNNN.so = 16-row workgroups from NNNN rows down); what was kept: kPanelSmallRows = 4096, kPanelSmallXR = 16.
 R=$PWD
 O=$R/gpurun_out/r04g
 mkdir -p $O
