@@ -63,9 +63,7 @@ int aug_build(smn_ctx* ctx, const BuildSpec& spec, const Aug& g, const void* x, 
   SMN_TRY(smn_workspace(ctx, 0, g.es * (size_t)kp * (size_t)g.n_total + sizeof(double) * (size_t)g.n_total, &xs));
   double* q = static_cast<double*>(xs);
   char* xp = reinterpret_cast<char*>(q + g.n_total);
-  SMN_TRY(pad_rows(ctx, spec.dtype, x, g.n, ldx, d, xp, g.n_pad, kp, q));
-  SMN_TRY(pad_rows(ctx, spec.dtype, xt, g.t, ldxt, d, xp + g.es * (size_t)kp * (size_t)g.n_pad, g.n_total - g.n_pad, kp,
-                   q + g.n_pad));
+  SMN_TRY(pad_rows(ctx, spec.dtype, x, g.n, ldx, d, xp, g.n_total, kp, q, g.n_pad, xt, g.t, ldxt));   // both blocks in one launch
   BuildCall c{};
   c.spec = spec;
   c.x1p = xp; c.ld1 = kp; c.rows1 = g.n_total; c.q1 = q;

@@ -66,8 +66,11 @@ int run_build(smn_ctx* ctx, const BuildCall& c);
 int split_corner_tiles(const smn_ctx* ctx, int64_t tiles);
 
 // dst[rows_pad, kp] (ld = kp) <- zero-padded copy of src[n, d]; also q[rows_pad] = ||row||^2 / d.
+// rows_a > 0: rows [rows_a, rows_pad) are src2[n2, d] (zero-padded like the first block): one launch for both blocks of an
+// augmented operand
 int pad_rows(smn_ctx* ctx, int dtype, const void* src, int64_t n, int64_t lds, int64_t d,
-             void* dst, int64_t rows_pad, int64_t kp, double* q);
+             void* dst, int64_t rows_pad, int64_t kp, double* q, int64_t rows_a = 0, const void* src2 = nullptr, int64_t n2 = 0,
+             int64_t lds2 = 0);
 
 inline int64_t k_pad(int dtype, int64_t d) { return round_up(d, dtype == SMN_F64 ? 16 : 32); }
 

@@ -23,26 +23,33 @@ constexpr int64_t kHalfTileBuildMax = 600;   // f32 build launches of at most th
 template <typename T>
 __global__ void pad_rows_kernel(const T* __restrict__ src, int64_t n, int64_t lds, int64_t d,
                                 T* __restrict__ dst, int64_t rows_pad, int64_t kp, double inv_d,
-                                double* __restrict__ q) {
-  // one wave per padded row
+                                double* __restrict__ q, int64_t rows_a = 0, const T* __restrict__ src2 = nullptr,
+                                int64_t n2 = 0, int64_t lds2 = 0) {
+  // one wave per padded row; rows_a > 0: the rows from rows_a on come from a second matrix (the appended block of an
+  // augmented operand: one launch instead of two)
   const int lane = threadIdx.x & 63;
-  const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (row >= rows_pad) return;
+  dst += row * kp;
+  if (q) q += row;
+  if (rows_a > 0 && row >= rows_a) {
+    row -= rows_a; src = src2; n = n2; lds = lds2;
+  }
   double s = 0.0;
   for (int64_t c = lane; c < kp; c += 64) {
     T v = (row < n && c < d) ? src[row * lds + c] : T(0);
-    dst[row * kp + c] = v;
+    dst[c] = v;
     s += (double)v * (double)v;
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-  if (lane == 0 && q) q[row] = s * inv_d;
+  if (lane == 0 && q) *q = s * inv_d;
 }
 
 // Per-row tables.  tab[(set*2+0)*ldt + i] = r, tab[(set*2+1)*ldt + i] = s; dg[i] / dgt[i] = the
 // closed-form NNGP / NTK diagonal (c = 1: ReLU Kdot = 1/2, erf Kdot = 4 / (pi sqrt(1 + 4q))).
-template <typename T>
-__global__ void diag_tables_kernel(const double* __restrict__ q0, int64_t n, LayerProg p,
+template <typename T, typename Q = double>
+__global__ void diag_tables_kernel(const Q* __restrict__ q0, int64_t n, LayerProg p,
                                    T* __restrict__ tab, int64_t ldt, T* __restrict__ dg, T* __restrict__ dgt,
                                    const LayerProg* __restrict__ progs = nullptr, int64_t tab_bs = 0) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -51,7 +58,7 @@ __global__ void diag_tables_kernel(const double* __restrict__ q0, int64_t n, Lay
     p = progs[blockIdx.y];
     tab += (int64_t)blockIdx.y * tab_bs; dg += (int64_t)blockIdx.y * tab_bs; dgt += (int64_t)blockIdx.y * tab_bs;
   }
-  double q = q0[i], th = 0.0;
+  double q = (double)q0[i], th = 0.0;   // (Q = T: smn_recursion takes q in the compute type)
   if (p.net == NET_RESNET) {
     q = p.w2 * q + p.b2;
     th = q;
@@ -754,12 +761,6 @@ __global__ void cast_from_double_kernel(const double* __restrict__ s, T* __restr
   if (i < n) d[i] = (T)s[i];
 }
 template <typename T>
-__global__ void cast_to_double_kernel(const T* __restrict__ s, double* __restrict__ d, int64_t n, int64_t npad) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < npad) d[i] = i < n ? (double)s[i] : 0.0;
-}
-
-template <typename T>
 int recursion_t(smn_ctx* ctx, const BuildSpec& spec, const void* k0, int64_t n1, int64_t n2, int64_t ldk0,
                 const void* q1, const void* q2, int symmetric, int get_mask, void* nngp, void* ntk, int64_t ldk) {
   LayerProg prog;
@@ -770,23 +771,22 @@ int recursion_t(smn_ctx* ctx, const BuildSpec& spec, const void* k0, int64_t n1,
   const int trows = 2 * prog.nsets + 2;
   const int64_t tlen = n1 + n2;
   void* tabv = nullptr;
-  SMN_TRY(smn_workspace(ctx, 1, sizeof(T) * (size_t)trows * tlen + sizeof(double) * (size_t)tlen, &tabv));
-  double* qd = static_cast<double*>(tabv);
-  T* tab1 = reinterpret_cast<T*>(qd + tlen);
+  SMN_TRY(smn_workspace(ctx, 1, sizeof(T) * (size_t)trows * tlen, &tabv));
+  T* tab1 = static_cast<T*>(tabv);
   T* dg1 = tab1 + (int64_t)(2 * prog.nsets) * tlen;
   T* dgt1 = dg1 + tlen;
-  hipLaunchKernelGGL(cast_to_double_kernel<T>, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, ctx->stream,
-                     static_cast<const T*>(q1), qd, n1, n1);
-  hipLaunchKernelGGL(cast_to_double_kernel<T>, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, ctx->stream,
-                     static_cast<const T*>(q2), qd + n1, n2, n2);
-  hipLaunchKernelGGL(diag_tables_kernel<T>, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, ctx->stream,
-                     qd, n1, prog, tab1, tlen, dg1, dgt1);
-  hipLaunchKernelGGL(diag_tables_kernel<T>, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, ctx->stream,
-                     qd + n1, n2, prog, tab1 + n1, tlen, dg1 + n1, dgt1 + n1);
+  // one table launch per operand, straight from q in the compute type; the same operand on both sides (the gradient's
+  // symmetric call) shares one set of tables
+  const bool same = q1 == q2 && n1 == n2;
+  hipLaunchKernelGGL((diag_tables_kernel<T, T>), dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, ctx->stream,
+                     static_cast<const T*>(q1), n1, prog, tab1, tlen, dg1, dgt1, static_cast<const LayerProg*>(nullptr), (int64_t)0);
+  if (!same)
+    hipLaunchKernelGGL((diag_tables_kernel<T, T>), dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, ctx->stream,
+                       static_cast<const T*>(q2), n2, prog, tab1 + n1, tlen, dg1 + n1, dgt1 + n1, static_cast<const LayerProg*>(nullptr), (int64_t)0);
   SMN_CHECK_LAUNCH(ctx);
   RecArgs<T> a;
   a.k0 = static_cast<const T*>(k0); a.ldk0 = ldk0; a.n1 = n1; a.n2 = n2;
-  a.tab1 = tab1; a.tab2 = tab1 + n1; a.ldt1 = tlen; a.ldt2 = tlen; a.dg = dg1; a.dgt = dgt1;
+  a.tab1 = tab1; a.tab2 = same ? tab1 : tab1 + n1; a.ldt1 = tlen; a.ldt2 = tlen; a.dg = dg1; a.dgt = dgt1;
   a.prog = prog; a.exact_diag = symmetric;
   a.out_k = (get_mask & SMN_GET_NNGP) ? static_cast<T*>(nngp) : nullptr;
   a.out_t = want_ntk ? static_cast<T*>(ntk) : nullptr;
@@ -808,15 +808,17 @@ int recursion_t(smn_ctx* ctx, const BuildSpec& spec, const void* k0, int64_t n1,
 }  // namespace
 
 int pad_rows(smn_ctx* ctx, int dtype, const void* src, int64_t n, int64_t lds, int64_t d,
-             void* dst, int64_t rows_pad, int64_t kp, double* q) {
+             void* dst, int64_t rows_pad, int64_t kp, double* q, int64_t rows_a, const void* src2, int64_t n2, int64_t lds2) {
   const unsigned blocks = (unsigned)((rows_pad + 3) / 4);
   ProfScope ps(ctx, PROF_PREP, ctx->stream);
   if (dtype == SMN_F64)
     hipLaunchKernelGGL(pad_rows_kernel<double>, dim3(blocks), dim3(256), 0, ctx->stream, static_cast<const double*>(src),
-                       n, lds, d, static_cast<double*>(dst), rows_pad, kp, 1.0 / (double)d, q);
+                       n, lds, d, static_cast<double*>(dst), rows_pad, kp, 1.0 / (double)d, q, rows_a,
+                       static_cast<const double*>(src2), n2, lds2);
   else
     hipLaunchKernelGGL(pad_rows_kernel<float>, dim3(blocks), dim3(256), 0, ctx->stream, static_cast<const float*>(src),
-                       n, lds, d, static_cast<float*>(dst), rows_pad, kp, 1.0 / (double)d, q);
+                       n, lds, d, static_cast<float*>(dst), rows_pad, kp, 1.0 / (double)d, q, rows_a,
+                       static_cast<const float*>(src2), n2, lds2);
   SMN_CHECK_LAUNCH(ctx);
   return SMN_OK;
 }
