@@ -900,6 +900,32 @@ def test_spr_loss_and_test_nll(dtype, method, network):
     assert abs(model2.test_nll(xte.astype(dtype), yte.astype(dtype)) - rn) < tol_nll * max(1.0, abs(rn))
 
 
+@pytest.mark.parametrize("n,t", [(1, 1), (2, 3), (127, 1), (128, 2), (129, 5), (255, 1), (257, 130)])
+def test_loss_and_test_nll_at_the_smallest_sizes_and_the_tile_edges(n, t):
+    """One data point, one test point, and the sizes on either side of the 128-row tile edge (the padded rows are an identity block
+    the factorisation carries along; the test block straddles a tile at t = 130): SPR.loss and SPR.test_nll, both likelihoods,
+    fp64, against the oracle."""
+    from smnngp import nt_kernels
+    from smnngp.spax.kernels import NNGPKernel
+    from smnngp.spax.likelihoods import GaussianLikelihood, StudentTLikelihood
+    from smnngp.spax.models import SPR
+    rng = np.random.default_rng(1000 * n + t)
+    d = 4
+    x, y = rng.standard_normal((n, d)), rng.standard_normal(n)
+    xt, yt = rng.standard_normal((t, d)), rng.standard_normal(t)
+    hyp = dict(w_std=1.2, b_std=0.4, last_w_std=0.9, eps=5e-2, alpha=2.5, beta=1.5)
+    for method in ("gp", "tp"):
+        kernel = NNGPKernel(lambda w, b, l: nt_kernels.get_mlp_kernel(2, 1, act="erf", w_std=w, b_std=b, last_w_std=l),
+                            hyp["w_std"], hyp["b_std"], hyp["last_w_std"])
+        lik = GaussianLikelihood() if method == "gp" else StudentTLikelihood(hyp["alpha"], hyp["beta"])
+        model = SPR(kernel, lik, x, y, 0.3, 1.7, eps=hyp["eps"])
+        okw = dict(kernel="mlp", num_hiddens=2, act="erf", method=method, **hyp)
+        rl = O.spr_loss(x, y, **okw)
+        rn = O.spr_test_nll(x, y, xt, yt, 0.3, 1.7, **okw)
+        assert abs(model.loss() - rl) < 1e-9 * max(1.0, abs(rl)), (method, model.loss(), rl)
+        assert abs(model.test_nll(xt, yt) - rn) < 1e-6 * max(1.0, abs(rn)), (method, model.test_nll(xt, yt), rn)
+
+
 def test_not_pd_gives_nan_like_the_reference(L, ctx):
     """JAX's Cholesky returns NaN on a non-PD matrix and the driver notices later (train.py:211): no exception, NaN out,
     through the fused call (info = first bad pivot), the facade's likelihood on a device matrix, and the batched call."""
