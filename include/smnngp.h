@@ -227,6 +227,9 @@ int smn_debug_batch_bytes(smn_ctx* ctx, size_t bytes);
  * launch on the bulk stream, beside the first super-panel's panel chain (same tiles, same bits: only the order changes).
  * on = 0 switches that off (one launch, as every other entry point builds). */
 int smn_debug_split_build(smn_ctx* ctx, int on);
+/* Test hook: a panel workgroup of the factorisation carries up to max_passes groups of rows when there are more groups than CUs
+ * (default 4; the later groups ride through the solve alone; same bits).  1 = one group per workgroup. */
+int smn_debug_panel_passes(smn_ctx* ctx, int max_passes);
 int smn_spr_predict_batch(smn_ctx* ctx, int dtype, int net, int act, int num_hiddens, int nprob,
                           const double* w_std, const double* b_std, const double* last_w_std,
                           const void* x_d, int64_t n, int64_t ldx, const void* xt_d, int64_t t, int64_t ldxt,

@@ -84,6 +84,7 @@ PROTOTYPES = {
                               _vp, _vp, _i64, _vp, _pd, _pd, _pi],
     "smn_debug_batch_bytes": [_vp, _sz],
     "smn_debug_split_build": [_vp, C.c_int],
+    "smn_debug_panel_passes": [_vp, C.c_int],
     "smn_mixture_nll": [_vp, _i, _i, _i64, _vp, _vp, _pd, _pd, _pi, _pd, _d, _d, _i64, _i, _i, _pd, _pd, _pd],
     "smn_comm_unique_id": [C.c_char_p],
     "smn_lml_grad_terms": [_vp, _i, _i, _i, _i, _d, _d, _d, _vp, _i64, _i64, _vp, _vp, _i64, _vp, _d, _pd],

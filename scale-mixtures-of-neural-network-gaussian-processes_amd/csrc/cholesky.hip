@@ -123,7 +123,7 @@ constexpr int panel_threads(int xr) { return (PB + xr + 63) / 64 * 64; }   // on
 constexpr int kLeafTileLd(size_t elem) { return 16 + 16 / (int)elem; }
 template <typename T>
 constexpr size_t panelr_lds_bytes(int xr = PanelCfg<T>::XR) {
-  return sizeof(T) * ((size_t)(PB + xr) * PanelCfg<T>::LD + (size_t)(panel_threads(xr) / 64) * 16 * kLeafTileLd(sizeof(T)))
+  return sizeof(T) * ((size_t)(PB + xr) * PanelCfg<T>::LD + (size_t)(panel_threads(xr) / 64) * 16 * kLeafTileLd(sizeof(T)) + PB)   // (+ the PB reciprocal pivots)
 #ifdef SMN_PANEL_TIMING
          + 4096
 #endif
@@ -405,7 +405,7 @@ __global__ void __launch_bounds__(2 * panel_threads(XRV)) panelr_kernel(T* __res
                                                                           int64_t rbeg, int64_t n_total,
                                                                           double* __restrict__ logdet,
                                                                           int* __restrict__ info, T* __restrict__ ldiag_out,
-                                                                          int64_t id0, int64_t id1, int64_t bstride, int64_t lstride) {
+                                                                          int64_t id0, int64_t id1, int64_t bstride, int64_t lstride, int passes) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int XR = XRV, NTV = panel_threads(XRV), LD = PanelCfg<T>::LD;
   if (bstride) {   // batched factorisation: problem blockIdx.y has its own matrix, scalars and side buffer
@@ -422,8 +422,10 @@ __global__ void __launch_bounds__(2 * panel_threads(XRV)) panelr_kernel(T* __res
   static_assert(RT - 1 <= 2 * 2 * NW, "update() gives every wave at most two tiles");
   T* S = reinterpret_cast<T*>(smem);        // [PB + XR][LD]
   const int tid = threadIdx.x;
-  const int64_t rb = rbeg + (int64_t)blockIdx.x * XR;
-  if (id0 >= 0 && rb >= id0 && rb + XR <= id1 && rb - id0 >= j0 + PB) return;
+  // `passes` > 1 (launch_panel_x: more row groups than CUs): this workgroup carries `passes` consecutive groups of XR rows,
+  // the first one through the loop below, the others through the v-steps alone (further down)
+  const int64_t rb = rbeg + (int64_t)blockIdx.x * passes * XR;
+  if (id0 >= 0 && rb >= id0 && rb + XR <= id1 && rb - id0 >= j0 + PB) return;   // (identity hints: passes == 1)
   const int nx = (int)max((int64_t)0, min((int64_t)XR, n_total - rb));
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = M::frag_row(lane), fk = M::frag_k(lane);
@@ -527,12 +529,13 @@ __global__ void __launch_bounds__(2 * panel_threads(XRV)) panelr_kernel(T* __res
       if (dst[u]) *reinterpret_cast<vec_t*>(dst[u]) = buf[u];
   };
 #ifdef SMN_PANEL_TIMING   // timeline of wg 0 of the first panel: ticks (100 MHz) since kernel start, per block, per wave, 6 marks
-  int* const tlog = reinterpret_cast<int*>(S + ROWS * LD + NW * CB * kLeafTileLd(sizeof(T)));
+  int* const tlog = reinterpret_cast<int*>(S + ROWS * LD + NW * CB * kLeafTileLd(sizeof(T)) + PB);
   const long long tl0 = wall_clock64();
 #define TL(b, i) do { if (lane == 0 && blockIdx.x == 0 && j0 == 0) tlog[(wave * NB + (b)) * 6 + (i)] = (int)(wall_clock64() - tl0); } while (0)
 #else
 #define TL(b, i)
 #endif
+  T* const rinv = S + ROWS * LD + NW * CB * kLeafTileLd(sizeof(T));   // [PB] reciprocal pivots, kept for the later passes
   if (wave >= NW) {
     // ------------------------------------------------------------ helpers: stage-in of blocks 1..
     const int hid = tid - NTV;
@@ -644,8 +647,18 @@ __global__ void __launch_bounds__(2 * panel_threads(XRV)) panelr_kernel(T* __res
           }
         }
         TL(b, 0);
-        leaf::run(D, V);
+        T R[CB];
+        leaf::run(D, V, R);
         TL(b, 1);
+        if (passes > 1 && wave == NW - 1 && lane == 0) {   // (the last row wave takes part in every block)
+#pragma unroll
+          for (int q = 0; q < VPC; ++q) {
+            vec_t t;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) t[e] = R[q * VEC + e];
+            *reinterpret_cast<vec_t*>(&rinv[cb + q * VEC]) = t;
+          }
+        }
         if (in_s && row >= cb) {
 #pragma unroll
           for (int q = 0; q < VPC; ++q) {
@@ -678,6 +691,66 @@ __global__ void __launch_bounds__(2 * panel_threads(XRV)) panelr_kernel(T* __res
 #endif
 #undef TL
   store_out(NB - 1, tid, std::integral_constant<int, 2 * NTV>{});
+  // Later passes: the image holds L and rinv the reciprocal pivots, so XR more rows at a time ride through the same column
+  // operations without the factorisation -- per block the MFMA update of their tiles (K = the finished columns, the same
+  // K loop) and the leaf's v-steps alone.  The same instructions on the same operands as a first pass would run: the same
+  // bits, whatever `passes` is.
+  for (int p = 1; p < passes; ++p) {
+    const int64_t rbp = rb + (int64_t)p * XR;
+    if (rbp >= n_total) break;                                   // (uniform)
+    const int nxp = (int)min((int64_t)XR, n_total - rbp);
+    constexpr int RV = PB / VEC;
+    __syncthreads();                                             // the previous pass's rows have left the image
+    for (int idx = tid; idx < XR * RV; idx += 2 * NTV) {
+      const int r = idx / RV, c = (idx % RV) * VEC;
+      vec_t t;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) t[e] = T(0);
+      if (r < nxp) t = *reinterpret_cast<const vec_t*>(&a[(rbp + r) * lda + j0 + c]);
+      *reinterpret_cast<vec_t*>(&S[(PB + r) * LD + c]) = t;
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int b = 0; b < NB; ++b) {
+      const int cb = b * CB;
+      if (b > 0) {
+        update(cb, PB / M::TM);                                  // the appended tiles only
+        __syncthreads();
+      }
+      const int row = tid, r16 = lane & 15;
+      if (wave < NW && 64 * (wave + 1) > PB) {                   // row waves that hold appended rows
+        const int srow = row < ROWS ? row : ROWS - 1;
+        T D[CB], V[CB], R[CB];
+#pragma unroll
+        for (int q = 0; q < VPC; ++q) {
+          const vec_t v = *reinterpret_cast<const vec_t*>(&S[srow * LD + cb + q * VEC]);
+          const vec_t d = *reinterpret_cast<const vec_t*>(&S[(cb + r16) * LD + cb + q * VEC]);
+          const vec_t r = *reinterpret_cast<const vec_t*>(&rinv[cb + q * VEC]);
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) {
+            V[q * VEC + e] = v[e];
+            D[q * VEC + e] = d[e];
+            R[q * VEC + e] = r[e];
+          }
+        }
+        leaf::solve(D, R, V);
+        if (row >= PB && row < ROWS) {
+#pragma unroll
+          for (int q = 0; q < VPC; ++q) {
+            vec_t t;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) t[e] = V[q * VEC + e];
+            *reinterpret_cast<vec_t*>(&S[row * LD + cb + q * VEC]) = t;
+          }
+        }
+      }
+      __syncthreads();
+    }
+    for (int idx = tid; idx < XR * RV; idx += 2 * NTV) {
+      const int r = idx / RV, c = (idx % RV) * VEC;
+      if (r < nxp) *reinterpret_cast<vec_t*>(&a[(rbp + r) * lda + j0 + c]) = *reinterpret_cast<const vec_t*>(&S[(PB + r) * LD + c]);
+    }
+  }
   if (blockIdx.x == 0 && tid < 64) {
     // logdet += 2 sum_j log L_jj; info = first pivot that is not a positive number (d <= 0 came out of the leaf as NaN)
     const T d0 = S[tid * LD + tid], d1 = S[(tid + 64) * LD + tid + 64];
@@ -1130,9 +1203,18 @@ int launch_panel_x(smn_ctx* ctx, hipStream_t st, T* a, int64_t lda, int64_t j0, 
   if (ctx->panel_leaf && !prefactored) {
     ProfScope ps(ctx, PROF_PANEL, st);
     T* ldiag = reinterpret_cast<T*>(ctx->ws[3]) + (j0 / PB) * (int64_t)(PB * PB);
+    // f64, more row groups than CUs (16 rows per workgroup: from 4096 rows on): every workgroup re-factors the diagonal block,
+    // and a second round of them would do it all over again.  Instead each carries `passes` groups, the later ones through
+    // the solve alone (panelr_kernel).  Same bits.  Measured (profiles/r04_multipass_panel.txt): f64 N = 8192 6.24 -> 5.92 ms,
+    // N = 16384 32.6 -> 31.1 ms; more passes than groups / CUs lose (even under the look-ahead's contention), and the f32
+    // 128-row form gains nothing at N = 36864 (its workgroups already carry 128 rows): f64 only.
+    int passes = 1;
+    if (sizeof(T) == 8 && !batched && ctx->chol_id0 < 0 && (int64_t)grid > (int64_t)ctx->num_cu)
+      passes = (int)std::min<int64_t>(((int64_t)grid + ctx->num_cu - 1) / ctx->num_cu, (int64_t)ctx->panel_max_passes);
+    const unsigned gridp = (grid + (unsigned)passes - 1) / (unsigned)passes;
     auto kernr = panelr_kernel<T, XRV>;
-    hipLaunchKernelGGL(kernr, dim3(grid, gy), dim3(2 * panel_threads(XRV)), panelr_lds_bytes<T>(XRV), st, a, lda, j0, rbeg, n_total,
-                       logdet, info, ldiag, ctx->chol_id0, ctx->chol_id1, bs, ls);
+    hipLaunchKernelGGL(kernr, dim3(gridp, gy), dim3(2 * panel_threads(XRV)), panelr_lds_bytes<T>(XRV), st, a, lda, j0, rbeg, n_total,
+                       logdet, info, ldiag, ctx->chol_id0, ctx->chol_id1, bs, ls, passes);
     SMN_CHECK_LAUNCH(ctx);
     return SMN_OK;
   }

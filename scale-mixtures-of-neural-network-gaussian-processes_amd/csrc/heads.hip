@@ -765,6 +765,12 @@ int spr_batch(smn_ctx* ctx, const char* who, int dtype, int net, int act, int nu
 }  // namespace
 
 // Test hook: the workspace budget of one batched pass (default 48 GB; larger batches run in chunks of what fits).
+extern "C" int smn_debug_panel_passes(smn_ctx* ctx, int max_passes) {
+  if (!ctx || max_passes < 1 || max_passes > 64) return SMN_EINVAL;
+  ctx->panel_max_passes = max_passes;
+  return SMN_OK;
+}
+
 extern "C" int smn_debug_split_build(smn_ctx* ctx, int on) {
   if (!ctx) return SMN_EINVAL;
   ctx->split_build = on != 0;

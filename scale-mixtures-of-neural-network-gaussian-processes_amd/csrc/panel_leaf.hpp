@@ -36,20 +36,32 @@ __device__ __forceinline__ double rsqrt_pivot(double d) {
   return __builtin_fma(y * e, __builtin_fma(0.375, e, 0.5), y);
 }
 
-#define LEAF_RINV(K) rinv = rsqrt_pivot(bcast<K>(D[K]));
+#define LEAF_RINV(K) R[K] = rsqrt_pivot(bcast<K>(D[K]));
 
-__device__ __forceinline__ void run(float (&D)[16], float (&V)[16]) {
-  float rinv;
+// R[k] = 1/sqrt(d_kk) of every step stays with the caller (a multi-pass panel workgroup stores them for its later passes).
+__device__ __forceinline__ void run(float (&D)[16], float (&V)[16], float (&R)[16]) {
 #define LEAF_STEPS_F32
 #include "panel_leaf_steps.inc"
 #undef LEAF_STEPS_F32
 }
-__device__ __forceinline__ void run(double (&D)[16], double (&V)[16]) {
-  double rinv;
+__device__ __forceinline__ void run(double (&D)[16], double (&V)[16], double (&R)[16]) {
 #define LEAF_STEPS_F64
 #include "panel_leaf_steps.inc"
 #undef LEAF_STEPS_F64
 }
 #undef LEAF_RINV
+
+// The v-steps alone: the lane's own row carried through a tile that is already factored (D = rows of L, R = the reciprocal
+// pivots the factoring pass kept).  The instructions of the fused leaf's v-steps on the same operands: the same bits.
+__device__ __forceinline__ void solve(const float (&D)[16], const float (&R)[16], float (&V)[16]) {
+#define LEAF_SOLVE_F32
+#include "panel_leaf_steps.inc"
+#undef LEAF_SOLVE_F32
+}
+__device__ __forceinline__ void solve(const double (&D)[16], const double (&R)[16], double (&V)[16]) {
+#define LEAF_SOLVE_F64
+#include "panel_leaf_steps.inc"
+#undef LEAF_SOLVE_F64
+}
 
 }  // namespace leaf

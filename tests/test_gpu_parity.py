@@ -664,6 +664,33 @@ def test_panel_register_leaf_agrees_with_the_lds_micro_panel_kernel(L, dtype, n,
     assert out[1][0] == out[2][0] and np.array_equal(out[1][1][il], out[2][1][il])
 
 
+@pytest.mark.parametrize("n,m", [(6144, 128), (4352, 0)])
+def test_multi_pass_panel_workgroups_give_the_one_group_bits(L, ctx, n, m):
+    """fp64 panels carry 16 rows per workgroup; with more row groups than CUs a workgroup takes several, the later ones through
+    the MFMA update of their tile and the leaf's v-steps alone (cholesky.hip panelr_kernel `passes`).  Same instructions on the
+    same operands: the factor of the one-group-per-workgroup launch bit for bit (384 groups -> two passes; 264 -> two, the
+    second one partly empty), and LAPACK's to rounding."""
+    rng = np.random.default_rng(n)
+    g = rng.standard_normal((n + m, 48))
+    a = g @ g.T / 48 + np.diag(rng.uniform(1.0, 2.0, n + m))
+    out = []
+    try:
+        for passes in (4, 1, 4):
+            ctx.call("smn_debug_panel_passes", passes)
+            ad = ctx.to_device(a)
+            info, logdet = C.c_int(), C.c_double()
+            ctx.call("smn_cholesky", L.F64, ad.ptr, n + m, n, n + m, 0, 0.0, 0.0, C.byref(info), C.byref(logdet))
+            assert info.value == 0
+            out.append((logdet.value, ad.numpy()))
+    finally:
+        ctx.call("smn_debug_panel_passes", 4)
+    il = np.tril_indices(n + m)
+    assert out[0][0] == out[1][0] == out[2][0]
+    assert np.array_equal(out[0][1][il], out[1][1][il]) and np.array_equal(out[0][1][il], out[2][1][il])
+    ref = np.linalg.cholesky(a[:n, :n])
+    assert np.abs(np.tril(out[0][1][:n, :n]) - ref).max() < 1e-11
+
+
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_split_build_of_the_fused_loss_gives_the_single_launch_bits(L, ctx, dtype):
     """smn_spr_loss from 112 tile rows on (look-ahead on) builds the bottom-right corner of the kernel matrix as a second launch
