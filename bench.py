@@ -1089,10 +1089,14 @@ def main():
                                       "so ms_per_step is Amdahl-bound" % chol_wall_ms)
             # the same shape's fused lower build on ONE GPU, measured here and now on this rank (one un-sharded step), for the ratio
             try:
-                ctx.call("smn_profile_enable", 2 << 1)
-                for _ in range(2):
-                    ctx.call("smn_spr_loss", code, L.NET_MLP, act, nl, 1.0, 1e-8, 1.0, x.ptr, n, d, d, y.ptr, eps, 0.0, 1.0,
-                             C.byref(lp), C.byref(quad), C.byref(logdet), C.byref(info))
+                ctx.call("smn_debug_split_build", 0)      # ONE build launch with the chip to itself (the fused call otherwise
+                ctx.call("smn_profile_enable", 2 << 1)    # builds the matrix's corner beside the first panel chain)
+                try:
+                    for _ in range(2):
+                        ctx.call("smn_spr_loss", code, L.NET_MLP, act, nl, 1.0, 1e-8, 1.0, x.ptr, n, d, d, y.ptr, eps, 0.0, 1.0,
+                                 C.byref(lp), C.byref(quad), C.byref(logdet), C.byref(info))
+                finally:
+                    ctx.call("smn_debug_split_build", 1)
                 ms1, cnt1 = C.c_double(), C.c_int()
                 ctx.call("smn_profile_read", 1, C.byref(ms1), C.byref(cnt1))
                 ctx.call("smn_profile_enable", 0)

@@ -70,6 +70,19 @@ def test_sharded_path_on_a_one_rank_communicator_equals_the_fused_step():
     assert b["exchange_ranges"] >= 2 and b["scaling"] == "strong"
 
 
+def test_one_gpu_build_reference_of_the_sharded_line_is_one_launch():
+    """From 112 tile rows on the fused single-GPU call builds the matrix in TWO launches (the corner beside the first panel chain);
+    the sharded line's reference for `build_only_speedup` must be the one-launch build with the chip to itself, not the average of
+    the two launches: with one rank the ratio is about 1."""
+    big = ["--n", "14400", "--d", "256", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-recursion-probe",
+           "--no-exclusive-probe", "--no-other-workloads", "--sharded-path"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + big, capture_output=True, text=True, timeout=420, env=env)
+    assert r.returncode == 0, r.stderr[-1500:]
+    b = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][0])
+    assert 0.75 < b["build_only_speedup"] < 1.35, (b["build_only_speedup"], b["one_gpu_build_ms"], b["kernel_build_ms"])
+
+
 @pytest.mark.parametrize("config", ["c4", "c5"])
 def test_two_ranks_on_two_devices_equal_the_single_gpu_step(config):
     if _devices() < 2:
