@@ -115,13 +115,16 @@ __global__ void set_aug_rows_kernel(T* __restrict__ a, int64_t lda, int64_t row0
 template <typename T>
 __global__ void aug_prep_kernel(T* __restrict__ a, int64_t lda, int64_t row0, int64_t col0, int64_t ncols, const T* __restrict__ y,
                                 int64_t n, int64_t c, int64_t ldy, int64_t n_shift, double jitter_abs,
-                                double* __restrict__ logdet, int* __restrict__ info) {
+                                double* __restrict__ logdet, int* __restrict__ info, double ridge_rel, int64_t n_trace) {
   const int64_t i = col0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // columns [col0, ncols) (a split build preps its corner later)
   const int64_t k = blockIdx.y;
   if (i >= ncols || k >= c) return;
   a[(row0 + k) * lda + i] = i < n ? y[i * ldy + k] : T(0);
   if (k == 0) {
-    if (i < n_shift) a[i * lda + i] = (T)((double)a[i * lda + i] + jitter_abs);
+    if (i < n_shift) {   // (the arithmetic of diag_shift_kernel; the trace sits next to logdet)
+      const double sh = jitter_abs + (ridge_rel != 0.0 ? ridge_rel * logdet[1] / (double)n_trace : 0.0);
+      a[i * lda + i] = (T)((double)a[i * lda + i] + sh);
+    }
     if (i == 0) {
       *logdet = 0.0;
       *info = INT_MAX;
@@ -241,13 +244,13 @@ int extract_posterior(smn_ctx* ctx, int dtype, const void* a, int64_t lda, int64
 }
 
 int aug_prep(smn_ctx* ctx, int dtype, void* a, int64_t lda, int64_t row0, int64_t ncols, const void* y, int64_t n,
-             int64_t c, int64_t ldy, int64_t n_shift, double jitter_abs, int64_t col0, hipStream_t st) {
+             int64_t c, int64_t ldy, int64_t n_shift, double jitter_abs, int64_t col0, hipStream_t st, double ridge_rel, int64_t n_trace) {
   if (c <= 0 || n_shift > ncols || col0 < 0 || col0 >= ncols) return smn_fail(ctx, SMN_EINVAL, "aug_prep: bad sizes");
   if (!st) st = ctx->stream;
   dim3 g((unsigned)((ncols - col0 + 255) / 256), (unsigned)c);
   DISPATCH_T(dtype,
-             hipLaunchKernelGGL(aug_prep_kernel<float>, g, dim3(256), 0, st, static_cast<float*>(a), lda, row0, col0, ncols, static_cast<const float*>(y), n, c, ldy, n_shift, jitter_abs, ctx->d_scal, ctx->d_info),
-             hipLaunchKernelGGL(aug_prep_kernel<double>, g, dim3(256), 0, st, static_cast<double*>(a), lda, row0, col0, ncols, static_cast<const double*>(y), n, c, ldy, n_shift, jitter_abs, ctx->d_scal, ctx->d_info));
+             hipLaunchKernelGGL(aug_prep_kernel<float>, g, dim3(256), 0, st, static_cast<float*>(a), lda, row0, col0, ncols, static_cast<const float*>(y), n, c, ldy, n_shift, jitter_abs, ctx->d_scal, ctx->d_info, ridge_rel, n_trace),
+             hipLaunchKernelGGL(aug_prep_kernel<double>, g, dim3(256), 0, st, static_cast<double*>(a), lda, row0, col0, ncols, static_cast<const double*>(y), n, c, ldy, n_shift, jitter_abs, ctx->d_scal, ctx->d_info, ridge_rel, n_trace));
   SMN_CHECK_LAUNCH(ctx);
   return SMN_OK;
 }

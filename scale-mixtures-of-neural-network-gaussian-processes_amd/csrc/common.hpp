@@ -71,6 +71,7 @@ struct smn_ctx {
   // chain, which needs none of it; the factorisation takes it as one Arrival.  The two tile orders live in tile_list.
   int* tile_list = nullptr; int64_t tile_list_cap = 0; int tile_list_tm = 0, tile_list_tb = 0, tile_list_na = 0, tile_list_nb = 0;
   hipEvent_t ev_s0 = nullptr, ev_corner = nullptr;   // main -> bulk (the first launch is done); bulk -> main (the corner has landed)
+  bool trace_ready = false;          // the build in front left the trace of the kernel's diagonal in d_scal[1] (BuildCall::want_trace)
   bool split_build = true;           // smn_debug_split_build
   int panel_max_passes = 4;          // row groups one panel workgroup may carry (smn_debug_panel_passes; 1: one group each, as before round 4)
   int64_t corner_col = 0;            // first column of the corner of the split build in flight (0: none)

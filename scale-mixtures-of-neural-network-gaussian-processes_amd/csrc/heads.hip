@@ -57,7 +57,7 @@ double logpdf_from(double quad, double logdet, int64_t n, double df, double scal
 // bottom-right corner of the matrix is then built on the bulk stream beside the first super-panel's panel chain (run_build).
 int aug_build(smn_ctx* ctx, const BuildSpec& spec, const Aug& g, const void* x, int64_t ldx, const void* xt,
               int64_t ldxt, int64_t d, int nbatch = 0, const double* bw = nullptr, const double* bb = nullptr,
-              const double* blw = nullptr, bool allow_split = false) {
+              const double* blw = nullptr, bool allow_split = false, bool want_trace = false) {
   const int64_t kp = k_pad(spec.dtype, d);
   void* xs = nullptr;
   SMN_TRY(smn_workspace(ctx, 0, g.es * (size_t)kp * (size_t)g.n_total + sizeof(double) * (size_t)g.n_total, &xs));
@@ -77,6 +77,7 @@ int aug_build(smn_ctx* ctx, const BuildSpec& spec, const Aug& g, const void* x, 
   c.nbatch = nbatch; c.bw = bw; c.bb = bb; c.blw = blw; c.out_bs = g.n_total * g.lda;   // batched: problem b at a + b * n_total^2
   // (not while pieces of a column-first exchange are pending on this context: the Arrival list is theirs)
   c.split_corner = (allow_split && nbatch == 0 && ctx->split_build && ctx->arrivals.empty()) ? split_corner_tiles(ctx, g.n_total / kTile) : 0;
+  c.want_trace = (want_trace && nbatch == 0) ? 1 : 0;   // (relative ridge: the prep launch then carries the shift, aug_finish)
   return run_build(ctx, c);
 }
 
@@ -84,8 +85,12 @@ int aug_finish(smn_ctx* ctx, int dtype, const Aug& g, const void* y, int64_t ldy
                double ridge_rel, void* mean, void* cov, int64_t ldcov, double* quad_h, double* logdet_h, int* info_h,
                bool td_identity = false) {
   if (g.c > 48) return smn_fail(ctx, SMN_ENOTSUP, "more than 48 output columns");   // the mailbox holds 62 doubles
-  // with an absolute jitter only, the right-hand-side rows, the diagonal shift and the scalar reset are one launch
-  const bool prepped = ridge_rel == 0.0 && g.c > 0;
+  // the right-hand-side rows, the diagonal shift and the scalar reset are one launch: with an absolute jitter only, or with the
+  // relative ridge when the build in front left the trace of the kernel's diagonal (aug_build want_trace)
+  const bool traced = ctx->trace_ready;
+  ctx->trace_ready = false;
+  const bool prepped = g.c > 0 && (ridge_rel == 0.0 || traced);
+  const int64_t n_sh = (jitter_abs != 0.0 || ridge_rel != 0.0) ? n_shift : 0;
   // a split build (aug_build): the corner's columns are prepped behind the corner's own launch, on the bulk stream, and the
   // factorisation takes them as ONE arrival (cholesky.hip need_columns: whoever first touches those columns waits for it)
   const int64_t corner = ctx->corner_col;
@@ -93,9 +98,9 @@ int aug_finish(smn_ctx* ctx, int dtype, const Aug& g, const void* y, int64_t ldy
   if (corner > 0 && !prepped) SMN_HIP(ctx, hipStreamSynchronize(ctx->stream_bulk));   // (no caller does this: the trace needs every column)
   const bool split = corner > 0 && prepped && !ctx->consume_arrivals;
   if (split) {
-    const int64_t sh = jitter_abs != 0.0 ? n_shift : 0;
-    SMN_TRY(aug_prep(ctx, dtype, g.a, g.lda, g.n_pad + g.t, corner, y, g.n, g.c, ldy, std::min(sh, corner), jitter_abs));
-    const int prc = aug_prep(ctx, dtype, g.a, g.lda, g.n_pad + g.t, g.n_total, y, g.n, g.c, ldy, sh, jitter_abs, corner, ctx->stream_bulk);
+    const int64_t sh = n_sh;
+    SMN_TRY(aug_prep(ctx, dtype, g.a, g.lda, g.n_pad + g.t, corner, y, g.n, g.c, ldy, std::min(sh, corner), jitter_abs, 0, nullptr, ridge_rel, n_shift));
+    const int prc = aug_prep(ctx, dtype, g.a, g.lda, g.n_pad + g.t, g.n_total, y, g.n, g.c, ldy, sh, jitter_abs, corner, ctx->stream_bulk, ridge_rel, n_shift);
     if (prc != SMN_OK) {
       (void)hipStreamSynchronize(ctx->stream_bulk);
       return prc;
@@ -106,7 +111,7 @@ int aug_finish(smn_ctx* ctx, int dtype, const Aug& g, const void* y, int64_t ldy
     ctx->consume_arrivals = true;
   } else if (prepped) {
     if (corner > 0) SMN_HIP(ctx, hipStreamSynchronize(ctx->stream_bulk));
-    SMN_TRY(aug_prep(ctx, dtype, g.a, g.lda, g.n_pad + g.t, g.n_total, y, g.n, g.c, ldy, jitter_abs != 0.0 ? n_shift : 0, jitter_abs));
+    SMN_TRY(aug_prep(ctx, dtype, g.a, g.lda, g.n_pad + g.t, g.n_total, y, g.n, g.c, ldy, n_sh, jitter_abs, 0, nullptr, ridge_rel, n_shift));
   } else {
     SMN_TRY(set_aug_rows(ctx, dtype, g.a, g.lda, g.n_pad + g.t, g.n_total, y, g.n, g.c, ldy));
   }
@@ -834,6 +839,6 @@ extern "C" int smn_spr_predict(smn_ctx* ctx, int dtype, int net, int act, int nu
   Aug g;
   SMN_TRY(aug_alloc(ctx, dtype, n, t, c, &g));
   BuildSpec s{dtype, net, act, num_hiddens, w_std, b_std, last_w_std};
-  SMN_TRY(aug_build(ctx, s, g, x_d, ldx, t > 0 ? xt_d : x_d, t > 0 ? ldxt : ldx, d));
+  SMN_TRY(aug_build(ctx, s, g, x_d, ldx, t > 0 ? xt_d : x_d, t > 0 ? ldxt : ldx, d, 0, nullptr, nullptr, nullptr, true, ridge_rel != 0.0));
   return aug_finish(ctx, dtype, g, y_d, c, n, ridge_abs, ridge_rel, mean_d, cov_d, ldcov, quad_h, logdet_h, info_h);
 }

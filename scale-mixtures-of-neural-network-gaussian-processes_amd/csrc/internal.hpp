@@ -60,6 +60,8 @@ struct BuildCall {
   // split_corner = TB > 0 (symmetric, un-sharded, one problem): the tiles with row AND column >= T - TB go out as a second
   // launch on the bulk stream; ctx->corner_col / ev_corner tell the factorisation (cholesky.hip need_columns) when they landed
   int split_corner;
+  // want_trace: leave sum_i<nv0 K_ii (from the exact-diagonal table) in ctx->d_scal[1] and set ctx->trace_ready
+  int want_trace;
 };
 int run_build(smn_ctx* ctx, const BuildCall& c);
 // TB for a split build of T tile rows on this context (0: do not split)
@@ -110,8 +112,10 @@ int extract_posterior(smn_ctx* ctx, int dtype, const void* a, int64_t lda, int64
 // set_aug_rows + absolute diagonal shift + reset of logdet / info in one launch (cholesky_padded then runs with
 // ctx->chol_prepped set and skips its own two)
 // (columns [col0, ncols) only, on stream st: the corner of a split build is prepped behind its own launch)
+// ridge_rel != 0: the shift is jitter_abs + ridge_rel * d_scal[1] / n_trace (the trace left there by the build: want_trace)
 int aug_prep(smn_ctx* ctx, int dtype, void* a, int64_t lda, int64_t row0, int64_t ncols, const void* y, int64_t n,
-             int64_t c, int64_t ldy, int64_t n_shift, double jitter_abs, int64_t col0 = 0, hipStream_t st = nullptr);
+             int64_t c, int64_t ldy, int64_t n_shift, double jitter_abs, int64_t col0 = 0, hipStream_t st = nullptr,
+             double ridge_rel = 0.0, int64_t n_trace = 0);
 // the mailbox after a launch that published into it (extract_posterior(..., publish = true)): synchronise and read
 int fetch_mail(smn_ctx* ctx, int nq, double* quad_h, double* logdet, int* info);
 int solve_rows_padded(smn_ctx* ctx, int dtype, void* a, int64_t n_total, int64_t n_factor, int64_t lda);

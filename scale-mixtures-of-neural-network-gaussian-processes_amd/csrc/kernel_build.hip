@@ -111,6 +111,23 @@ __global__ void diag_tables_kernel(const Q* __restrict__ q0, int64_t n, LayerPro
   dgt[i] = p.fast ? (T)(sqrt(p.lw2) * (p.nsets > 0 ? s_prev : 1.0)) : (T)th;
 }
 
+// sum of the exact diagonal dg[0, n) -- what diag_trace_kernel (cholesky.hip) reads off the built matrix, from the table the build
+// takes it from: the same values summed by the same tree (the relative ridge of the predictive path needs the trace BEFORE
+// the matrix exists when the prep launch is to carry the shift, and the matrix's diagonal is a 4-byte read per cache line)
+template <typename T>
+__global__ void table_trace_kernel(const T* __restrict__ dg, int64_t n, double* __restrict__ out) {
+  __shared__ double red[256];
+  double s = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += 256) s += (double)dg[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *out = red[0];
+}
+
 // ------------------------------------------------------------------ fused Gram + recursion
 template <typename T>
 struct BuildArgs {
@@ -637,6 +654,12 @@ int run_build_t(smn_ctx* ctx, const BuildCall& c) {
   hipLaunchKernelGGL(diag_tables_kernel<T>, dim3((unsigned)((c.rows1 + 255) / 256), (unsigned)nb), dim3(256), 0, ctx->stream,
                      c.q1, c.rows1, prog, tab1, tlen, dg1, dgt1, progs_d, tab_bs);
   SMN_CHECK_LAUNCH(ctx);
+  ctx->trace_ready = false;
+  if (c.want_trace && c.symmetric && c.exact_diag && c.nbatch == 0 && !c.shard && c.nv0 > 0) {
+    hipLaunchKernelGGL(table_trace_kernel<T>, dim3(1), dim3(256), 0, ctx->stream, dg1, c.nv0, ctx->d_scal + 1);
+    SMN_CHECK_LAUNCH(ctx);
+    ctx->trace_ready = true;
+  }
   T* tab2 = tab1;
   if (!c.symmetric) {
     tab2 = tab1 + c.rows1;
