@@ -695,20 +695,30 @@ __global__ void __launch_bounds__(2 * panel_threads(XRV)) panelr_kernel(T* __res
   // operations without the factorisation -- per block the MFMA update of their tiles (K = the finished columns, the same
   // K loop) and the leaf's v-steps alone.  The same instructions on the same operands as a first pass would run: the same
   // bits, whatever `passes` is.
+  constexpr int RV = PB / VEC, PRE = (XR * RV + 2 * NTV - 1) / (2 * NTV);
+  vec_t pre[PRE];                                                // the NEXT pass's raw rows, in flight while this pass runs
+  auto prefetch = [&](int p) {
+    const int64_t rbp = rb + (int64_t)p * XR;
+#pragma unroll
+    for (int u = 0; u < PRE; ++u) {
+      const int idx = u * 2 * NTV + tid, r = idx / RV, c = (idx % RV) * VEC;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) pre[u][e] = T(0);
+      if (idx < XR * RV && rbp + r < n_total) pre[u] = *reinterpret_cast<const vec_t*>(&a[(rbp + r) * lda + j0 + c]);
+    }
+  };
+  if (passes > 1) prefetch(1);
   for (int p = 1; p < passes; ++p) {
     const int64_t rbp = rb + (int64_t)p * XR;
     if (rbp >= n_total) break;                                   // (uniform)
     const int nxp = (int)min((int64_t)XR, n_total - rbp);
-    constexpr int RV = PB / VEC;
     __syncthreads();                                             // the previous pass's rows have left the image
-    for (int idx = tid; idx < XR * RV; idx += 2 * NTV) {
-      const int r = idx / RV, c = (idx % RV) * VEC;
-      vec_t t;
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) t[e] = T(0);
-      if (r < nxp) t = *reinterpret_cast<const vec_t*>(&a[(rbp + r) * lda + j0 + c]);
-      *reinterpret_cast<vec_t*>(&S[(PB + r) * LD + c]) = t;
+    for (int u = 0; u < PRE; ++u) {
+      const int idx = u * 2 * NTV + tid, r = idx / RV, c = (idx % RV) * VEC;
+      if (idx < XR * RV) *reinterpret_cast<vec_t*>(&S[(PB + r) * LD + c]) = pre[u];
     }
+    if (p + 1 < passes) prefetch(p + 1);
     __syncthreads();
 #pragma unroll 1
     for (int b = 0; b < NB; ++b) {
